@@ -1,0 +1,511 @@
+/*
+ * mlggd_oracle.c -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * Plain-C restatement of the reference device path, kernel for kernel, in the order the
+ * reference issues them.  Every function cites the reference file:line it follows
+ * (paths relative to /root/reference/Train_code_ML_GGD/).  See mlggd_oracle.h for the
+ * parity status ("parity unpinned" at the cuBLAS / CUDA-libm boundary).
+ *
+ * Decisions for ambiguities no reference run can settle (SURVEY.md 8a i-vii):
+ *  (i)   pow/fabs/abs/log on float arguments inside the .cu files are the float
+ *        overloads (powf/fabsf/logf), as nvcc resolves them.
+ *  (ii)  cublasSgemm summation order is unspecified; this oracle fixes one order per GEMM
+ *        (documented at each gemm_* below) and computes C = alpha*(A.B) + beta*C, i.e. the
+ *        dot product is formed from 0.0f and the old C (the broadcast bias) is added last.
+ *  (iii) dX uses the weights from before this step's update ("old weights").
+ *  (iv)  the gradient is divided by n_frames twice (loss gradient and update).
+ *  (vi)  CrossValid2 uses the alpha of the last training minibatch.
+ *  (vii) delta buffers start at zero.
+ * Built with -ffp-contract=off so no a*b+c is fused; OpenMP only splits independent
+ * output elements across threads, so results do not depend on the thread count.
+ */
+#include "mlggd_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+struct ora_net {
+    int numlayers;
+    int layersizes[ORA_MAXLAYER];
+    int bunchsize;
+    float lrate, momentum, weightcost, shapefactor;
+    int MLflag;
+    /* BP_WorkSpace, BP_GPU.h:17-43 (only the members the train step uses) */
+    float *out, *realerror, *errorabsolute, *errorabsolute2, *newobj;
+    float *vec1, *vec2, *scalefactor;
+    float *weights[ORA_MAXLAYER], *bias[ORA_MAXLAYER];
+    float *delta_weights[ORA_MAXLAYER], *delta_bias[ORA_MAXLAYER];
+    float *layer_x[ORA_MAXLAYER], *layer_y[ORA_MAXLAYER];
+    float *layer_dedy[ORA_MAXLAYER], *layer_dedx[ORA_MAXLAYER];
+    float *layer_ydedx[ORA_MAXLAYER], *layer_sumdedx[ORA_MAXLAYER];
+    int cap_frames; /* rows allocated for the per-bunch buffers */
+};
+
+static float *zalloc(size_t n) { /* devnew_vf zero-fills, BP_GPU.cu:528-543 */
+    float *p = (float *)calloc(n ? n : 1, sizeof(float));
+    if (!p) abort();
+    return p;
+}
+
+int ora_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+static void alloc_bunch_buffers(ora_net *net, int frames) {
+    const int L = net->numlayers, D = net->layersizes[L - 1];
+    free(net->out); free(net->realerror); free(net->errorabsolute);
+    free(net->errorabsolute2); free(net->newobj);
+    net->out = zalloc((size_t)frames * D);
+    net->realerror = zalloc((size_t)frames * D);
+    net->errorabsolute = zalloc((size_t)frames * D);
+    net->errorabsolute2 = zalloc((size_t)frames * D);
+    net->newobj = zalloc((size_t)frames * D);
+    for (int l = 1; l < L; l++) {
+        const size_t sz = (size_t)frames * net->layersizes[l];
+        free(net->layer_x[l]); free(net->layer_y[l]);
+        free(net->layer_dedy[l]); free(net->layer_dedx[l]);
+        net->layer_x[l] = zalloc(sz);
+        net->layer_y[l] = zalloc(sz);
+        net->layer_dedy[l] = zalloc(sz);
+        net->layer_dedx[l] = zalloc(sz);
+    }
+    net->cap_frames = frames;
+}
+
+/* BP_GPU::BP_GPU, BP_GPU.cu:9-111 */
+ora_net *ora_create(int numlayers, const int *layersizes, int bunchsize, float lrate,
+                    float momentum, float weightcost, float shapefactor, int MLflag,
+                    const float *const *weights, const float *const *bias) {
+    if (numlayers < 2 || numlayers > ORA_MAXLAYER || bunchsize < 1) return NULL;
+    ora_net *net = (ora_net *)calloc(1, sizeof(ora_net));
+    net->numlayers = numlayers;
+    for (int i = 0; i < numlayers; i++) net->layersizes[i] = layersizes[i];
+    net->bunchsize = bunchsize;
+    net->lrate = lrate; net->momentum = momentum; net->weightcost = weightcost;
+    net->shapefactor = shapefactor; net->MLflag = MLflag;
+    const int D = layersizes[numlayers - 1];
+    net->vec1 = zalloc(D); net->vec2 = zalloc(D); net->scalefactor = zalloc(D);
+    for (int l = 1; l < numlayers; l++) {
+        const size_t wsz = (size_t)layersizes[l] * layersizes[l - 1];
+        net->weights[l] = zalloc(wsz);
+        net->delta_weights[l] = zalloc(wsz);
+        net->layer_ydedx[l] = zalloc(wsz);
+        net->bias[l] = zalloc(layersizes[l]);
+        net->delta_bias[l] = zalloc(layersizes[l]);
+        net->layer_sumdedx[l] = zalloc(layersizes[l]);
+        memcpy(net->weights[l], weights[l], wsz * sizeof(float)); /* :106 */
+        memcpy(net->bias[l], bias[l], layersizes[l] * sizeof(float)); /* :107 */
+    }
+    alloc_bunch_buffers(net, bunchsize);
+    return net;
+}
+
+void ora_destroy(ora_net *net) {
+    if (!net) return;
+    free(net->out); free(net->realerror); free(net->errorabsolute);
+    free(net->errorabsolute2); free(net->newobj);
+    free(net->vec1); free(net->vec2); free(net->scalefactor);
+    for (int l = 1; l < net->numlayers; l++) {
+        free(net->weights[l]); free(net->bias[l]);
+        free(net->delta_weights[l]); free(net->delta_bias[l]);
+        free(net->layer_x[l]); free(net->layer_y[l]);
+        free(net->layer_dedy[l]); free(net->layer_dedx[l]);
+        free(net->layer_ydedx[l]); free(net->layer_sumdedx[l]);
+    }
+    free(net);
+}
+
+static void ensure_frames(ora_net *net, int frames) {
+    if (frames > net->cap_frames) alloc_bunch_buffers(net, frames);
+}
+
+/* ---- GEMMs (DevFunc.h:49-87).  Each fixes ONE summation order (cuBLAS leaves it open). */
+
+/* SgemmNN, DevFunc.h:65-75 <- BP_GPU.cu:361,494 : X[B][N] = 1*(Y[B][K] . W[K][N]) + 1*X.
+ * Order: dot product over k = 0..K-1 ascending from 0.0f, then + old X (the bias). */
+static void gemm_fwd(int B, int K, int N, const float *Y, const float *W, float *X) {
+    enum { JB = 128 };
+    const int nblk = (N + JB - 1) / JB;
+#pragma omp parallel
+    {
+        float *acc = (float *)malloc((size_t)B * JB * sizeof(float));
+#pragma omp for schedule(dynamic, 1)
+        for (int jb = 0; jb < nblk; jb++) {
+            const int j0 = jb * JB, jw = (N - j0 < JB) ? N - j0 : JB;
+            memset(acc, 0, (size_t)B * JB * sizeof(float));
+            for (int k = 0; k < K; k++) {
+                const float *w = W + (size_t)k * N + j0;
+                for (int b = 0; b < B; b++) {
+                    const float yv = Y[(size_t)b * K + k];
+                    float *a = acc + (size_t)b * JB;
+                    for (int j = 0; j < jw; j++) a[j] += yv * w[j];
+                }
+            }
+            for (int b = 0; b < B; b++)
+                for (int j = 0; j < jw; j++) {
+                    float *x = X + (size_t)b * N + j0 + j;
+                    *x = acc[(size_t)b * JB + j] + *x;
+                }
+        }
+        free(acc);
+    }
+}
+
+/* SgemmTN, DevFunc.h:49-63 <- BP_GPU.cu:430 : dEdY[B][K] = dEdX[B][N] . W[K][N]^T (beta 0).
+ * Order: eight interleaved partial sums q = j mod 8, each over ascending j, combined as
+ * ((s0+s1)+(s2+s3))+((s4+s5)+(s6+s7)). */
+static void gemm_dx(int B, int K, int N, const float *dEdX, const float *W, float *dEdY) {
+#pragma omp parallel for schedule(static)
+    for (int k = 0; k < K; k++) {
+        const float *w = W + (size_t)k * N;
+        for (int b = 0; b < B; b++) {
+            const float *d = dEdX + (size_t)b * N;
+            float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            int j = 0;
+            for (; j + 8 <= N; j += 8)
+                for (int q = 0; q < 8; q++) s[q] += d[j + q] * w[j + q];
+            for (int q = 0; j + q < N; q++) s[q] += d[j + q] * w[j + q];
+            dEdY[(size_t)b * K + k] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+        }
+    }
+}
+
+/* SgemmNT, DevFunc.h:77-87 <- BP_GPU.cu:432 : G[K][N] = Y[B][K]^T . dEdX[B][N] (beta 0).
+ * Order: b = 0..B-1 ascending from 0.0f. */
+static void gemm_dw(int B, int K, int N, const float *Y, const float *dEdX, float *G) {
+#pragma omp parallel for schedule(static)
+    for (int k = 0; k < K; k++) {
+        float *g = G + (size_t)k * N;
+        for (int j = 0; j < N; j++) g[j] = 0.0f;
+        for (int b = 0; b < B; b++) {
+            const float yv = Y[(size_t)b * K + k];
+            const float *d = dEdX + (size_t)b * N;
+            for (int j = 0; j < N; j++) g[j] += yv * d[j];
+        }
+    }
+}
+
+/* ---- forward: BP_GPU.cu:334-369 (train) and :467-509 (cv) ---- */
+void ora_forward(ora_net *net, int n, const float *in) {
+    ensure_frames(net, n);
+    const int L = net->numlayers;
+    for (int l = 1; l < L; l++) {
+        const int N = net->layersizes[l], K = net->layersizes[l - 1];
+        const float *prev_y = (l == 1) ? in : net->layer_y[l - 1];
+        float *x = net->layer_x[l];
+        /* kernMultiCopy, DevFunc.cu:134-149 <- BP_GPU.cu:360 */
+        for (int b = 0; b < n; b++) memcpy(x + (size_t)b * N, net->bias[l], N * sizeof(float));
+        gemm_fwd(n, K, N, prev_y, net->weights[l], x); /* :361 */
+        if (l != L - 1) {
+            /* kernSigmoid, DevFunc.cu:36-51 <- :364 */
+            float *y = net->layer_y[l];
+            const size_t sz = (size_t)n * N;
+#pragma omp parallel for schedule(static)
+            for (size_t i = 0; i < sz; i++) y[i] = 1.0f / (1.0f + expf(-x[i]));
+        } else {
+            memcpy(net->out, x, (size_t)n * N * sizeof(float)); /* cudaMemcpy D2D, :367 */
+        }
+    }
+}
+
+/* Deverror + Devabsolutevalus + Devindex2 + DevSumcol: BP_GPU.cu:413-416
+ * (kernerror DevFunc.cu:399-409, kernabsolutevalus :186-191, kernindex2 :219-227,
+ *  kernSumcol :167-185: thread per column, rows summed sequentially in fp32). */
+void ora_loss_colsum(ora_net *net, int n, const float *targ, float *colsum) {
+    const int D = net->layersizes[net->numlayers - 1];
+    const float beta = net->shapefactor;
+    for (int b = 0; b < n; b++)
+        for (int d = 0; d < D; d++) {
+            const size_t i = (size_t)b * D + d;
+            net->realerror[i] = net->out[i] - targ[i];
+            net->errorabsolute[i] = fabsf(net->realerror[i]);
+            net->errorabsolute2[i] = powf(net->errorabsolute[i], beta);
+        }
+    for (int d = 0; d < D; d++) {
+        float s = net->errorabsolute2[d];
+        for (int b = 1; b < n; b++) s += net->errorabsolute2[(size_t)b * D + d];
+        colsum[d] = s;
+    }
+}
+
+/* Output-layer gradient, BP_GPU.cu:408-424.  colsum_global: sum over the whole (global)
+ * minibatch of |e|^beta per dimension (only read when MLflag==1). */
+void ora_loss_grad(ora_net *net, int n, int n_global, const float *targ, const float *colsum_global) {
+    const int L = net->numlayers, D = net->layersizes[L - 1];
+    const float beta = net->shapefactor;
+    float *dedx = net->layer_dedx[L - 1];
+    /* kernSubClean2, DevFunc.cu:376-398 <- :408 */
+    for (int b = 0; b < n; b++)
+        for (int d = 0; d < D; d++) {
+            const size_t i = (size_t)b * D + d;
+            const float o = net->out[i], t = targ[i];
+            float g;
+            if (o > t) g = beta * powf(o - t, beta - 1);
+            else if (o == t) g = 0;
+            else g = -beta * powf(t - o, beta - 1);
+            dedx[i] = g;
+        }
+    /* kernVecMulNum, DevFunc.cu:287-293 <- :409 */
+    const float inv_n = 1.0f / n_global;
+    for (size_t i = 0; i < (size_t)n * D; i++) dedx[i] = dedx[i] * inv_n;
+    if (net->MLflag == 1) {
+        /* :413-415 recomputed so the phase is self-contained (same values as colsum pass) */
+        for (size_t i = 0; i < (size_t)n * D; i++) net->realerror[i] = net->out[i] - targ[i];
+        /* kernDivide, DevFunc.cu:445-450 <- :417 ; kernVecMulNum <- :418 ; kernindex2 <- :420 */
+        const float nf = (float)n_global;
+        const float ppp = 1.0f / beta;
+        for (int d = 0; d < D; d++) {
+            net->vec1[d] = colsum_global[d] / nf;
+            net->vec2[d] = net->vec1[d] * beta;
+            net->scalefactor[d] = powf(net->vec2[d], ppp);
+        }
+        /* kernfunc2, DevFunc.cu:468-489 <- :422 */
+        for (int b = 0; b < n; b++)
+            for (int d = 0; d < D; d++) {
+                const size_t i = (size_t)b * D + d;
+                const float e = net->realerror[i];
+                float g;
+                if (e > 0) g = powf(e, beta - 1.0f) * beta / powf(net->scalefactor[d], beta);
+                else if (e == 0) g = 0;
+                else g = -powf(-e, beta - 1.0f) * beta / powf(net->scalefactor[d], beta);
+                net->newobj[i] = g;
+            }
+        /* kernVecMulNum <- :423 */
+        for (size_t i = 0; i < (size_t)n * D; i++) dedx[i] = net->newobj[i] * inv_n;
+    }
+}
+
+/* Backward without the weight update: BP_GPU.cu:371-438.  Because dX(l) reads W_l before
+ * the update of W_l is applied (old-weights semantics) and nothing else in
+ * the backward pass reads weights, "all gradients first, then all updates" is the same
+ * computation as the reference's per-layer interleaving. */
+void ora_backward(ora_net *net, int n, const float *in) {
+    const int L = net->numlayers;
+    for (int l = L - 1; l > 0; l--) {
+        const int N = net->layersizes[l], K = net->layersizes[l - 1];
+        const float *prev_y = (l == 1) ? in : net->layer_y[l - 1];
+        float *dedx = net->layer_dedx[l];
+        if (l != L - 1) {
+            /* kernDsigmoid, DevFunc.cu:53-71 <- :402 */
+            const float *y = net->layer_y[l], *dedy = net->layer_dedy[l];
+            const size_t sz = (size_t)n * N;
+#pragma omp parallel for schedule(static)
+            for (size_t i = 0; i < sz; i++) dedx[i] = (1.0f - y[i]) * y[i] * dedy[i];
+        }
+        if (l != 1) gemm_dx(n, K, N, dedx, net->weights[l], net->layer_dedy[l - 1]); /* :430 */
+        gemm_dw(n, K, N, prev_y, dedx, net->layer_ydedx[l]);                          /* :432 */
+        /* kernAccSumrow, DevFunc.cu:267-285 <- :434 (alpha 0, beta 1; rows summed in order) */
+        float *sum = net->layer_sumdedx[l];
+        for (int j = 0; j < N; j++) {
+            float s = sum[j] * 0.0f + 1.0f * dedx[j];
+            for (int b = 1; b < n; b++) s += 1.0f * dedx[(size_t)b * N + j];
+            sum[j] = s;
+        }
+    }
+}
+
+/* kernUpdatedelta (DevFunc.cu:490-507) + kernAccSum (:427-443) <- BP_GPU.cu:433-437 */
+void ora_apply_update(ora_net *net, int n_global) {
+    const int L = net->numlayers;
+    const float mom = net->momentum, lr = net->lrate, wc = net->weightcost;
+    const float zero = 0.0f;
+    for (int l = L - 1; l > 0; l--) {
+        const int N = net->layersizes[l], K = net->layersizes[l - 1];
+        const size_t wsz = (size_t)N * K;
+        float *dw = net->delta_weights[l], *w = net->weights[l];
+        const float *g = net->layer_ydedx[l];
+#pragma omp parallel for schedule(static)
+        for (size_t i = 0; i < wsz; i++) {
+            dw[i] = mom * dw[i] - lr * (g[i] / n_global + wc * w[i]);
+        }
+        float *db = net->delta_bias[l], *bb = net->bias[l];
+        const float *gb = net->layer_sumdedx[l];
+        for (int j = 0; j < N; j++) db[j] = mom * db[j] - lr * (gb[j] / n_global + zero * bb[j]);
+#pragma omp parallel for schedule(static)
+        for (size_t i = 0; i < wsz; i++) w[i] = dw[i] + 1.0f * w[i];
+        for (int j = 0; j < N; j++) bb[j] = db[j] + 1.0f * bb[j];
+    }
+}
+
+/* BP_GPU::train_bunch_single, BP_GPU.cu:308-440 */
+void ora_train_bunch(ora_net *net, int n, const float *in, const float *targ) {
+    const int D = net->layersizes[net->numlayers - 1];
+    ora_forward(net, n, in);
+    float *colsum = net->vec1; /* scratch; ora_loss_grad overwrites vec1 after reading */
+    float *tmp = NULL;
+    if (net->MLflag == 1) {
+        tmp = (float *)malloc(D * sizeof(float));
+        ora_loss_colsum(net, n, targ, tmp);
+        colsum = tmp;
+    }
+    ora_loss_grad(net, n, n, targ, colsum);
+    free(tmp);
+    ora_backward(net, n, in);
+    ora_apply_update(net, n);
+}
+
+/* BP_GPU::train, BP_GPU.cu:152-185 */
+int ora_train(ora_net *net, int n_frames, const float *in, const float *targ) {
+    const int K0 = net->layersizes[0], D = net->layersizes[net->numlayers - 1];
+    const int B = net->bunchsize;
+    int trained = 0;
+    for (int i = 0; i < n_frames; i += B) {
+        const int fb = (B > n_frames - i) ? (n_frames - i) : B;
+        if (fb == B) {
+            ora_train_bunch(net, fb, in, targ);
+            trained++;
+        } /* else: "this bunch has only %d samples and is ignored", :177-180 */
+        in += (size_t)K0 * fb;
+        targ += (size_t)D * fb;
+    }
+    return trained;
+}
+
+/* BP_GPU::cv_bunch_single, BP_GPU.cu:442-512 (dropoutflag==0 path) */
+void ora_cv_bunch(ora_net *net, int n, const float *in, float *out) {
+    const int D = net->layersizes[net->numlayers - 1];
+    ora_forward(net, n, in);
+    memcpy(out, net->out, (size_t)n * D * sizeof(float));
+}
+
+/* BP_GPU::CrossValid, BP_GPU.cu:187-219 */
+float ora_cv_sqerr(ora_net *net, int n_frames, const float *in, const float *targ) {
+    const int K0 = net->layersizes[0], D = net->layersizes[net->numlayers - 1], B = net->bunchsize;
+    float squared_err = 0.0f;
+    float *out = (float *)malloc((size_t)B * D * sizeof(float));
+    for (int i = 0; i < n_frames; i += B) {
+        const int fb = (B > n_frames - i) ? (n_frames - i) : B;
+        ora_cv_bunch(net, fb, in, out);
+        for (int j = 0; j < fb; j++)
+            for (int d = 0; d < D; d++)
+                squared_err = squared_err + (out[j * D + d] - targ[j * D + d]) * (out[j * D + d] - targ[j * D + d]);
+        in += (size_t)K0 * fb;
+        targ += (size_t)D * fb;
+    }
+    free(out);
+    return squared_err;
+}
+
+/* BP_GPU::CrossValiddB, BP_GPU.cu:220-253 */
+float ora_cv_abserr(ora_net *net, int n_frames, const float *in, const float *targ) {
+    const int K0 = net->layersizes[0], D = net->layersizes[net->numlayers - 1], B = net->bunchsize;
+    float squared_err = 0.0f;
+    float *out = (float *)malloc((size_t)B * D * sizeof(float));
+    for (int i = 0; i < n_frames; i += B) {
+        const int fb = (B > n_frames - i) ? (n_frames - i) : B;
+        ora_cv_bunch(net, fb, in, out);
+        for (int j = 0; j < fb; j++)
+            for (int d = 0; d < D; d++)
+                squared_err = squared_err + fabsf(out[j * D + d] - targ[j * D + d]);
+        in += (size_t)K0 * fb;
+        targ += (size_t)D * fb;
+    }
+    squared_err = squared_err / D;
+    free(out);
+    return squared_err;
+}
+
+/* BP_GPU::CrossValid2, BP_GPU.cu:254-306 */
+float ora_cv_loglik(ora_net *net, int n_frames, const float *in, const float *targ) {
+    const int K0 = net->layersizes[0], D = net->layersizes[net->numlayers - 1], B = net->bunchsize;
+    const float shapefactor = net->shapefactor;
+    float *err = (float *)malloc((size_t)n_frames * D * sizeof(float));
+    float *out = (float *)malloc((size_t)B * D * sizeof(float));
+    int h = 0;
+    for (int i = 0; i < n_frames; i += B) {
+        const int fb = (B > n_frames - i) ? (n_frames - i) : B;
+        ora_cv_bunch(net, fb, in, out);
+        for (int j = 0; j < fb; j++)
+            for (int d = 0; d < D; d++)
+                err[(size_t)(j + h) * D + d] = targ[j * D + d] - out[j * D + d];
+        in += (size_t)K0 * fb;
+        targ += (size_t)D * fb;
+        h = h + fb;
+    }
+    float density1, density2 = 0, density3 = 0, density;
+    const float *scalefac = net->scalefactor; /* fromdev_vf_vf(dev.scalefactor), :287 */
+    density1 = n_frames * D * logf(shapefactor / (2 * ora_gamma((float)(1.0 / shapefactor)))); /* :288 */
+    for (int u = 0; u < D; u++) density2 += logf(scalefac[u]);
+    density2 = density2 * n_frames;
+    for (int uu = 0; uu < n_frames; uu++)
+        for (int uuu = 0; uuu < D; uuu++)
+            density3 += powf(fabsf(err[(size_t)uu * D + uuu]) / scalefac[uuu], shapefactor);
+    density = density1 - density2 - density3;
+    free(out);
+    free(err);
+    return density;
+}
+
+/* BP_GPU::Gamma, BP_GPU.cu:593-640.  The polynomial terms are double expressions
+ * (x-2.0 and pow(double,double)); each statement rounds its sum to the float temp. */
+float ora_gamma(float x) {
+    if (x > 2 && x <= 3) {
+        const float c0 = 0.0000677106, c1 = -0.0003442342, c2 = 0.0015397681, c3 = -0.0024467480,
+                    c4 = 0.0109736958, c5 = -0.0002109075, c6 = 0.0742379071, c7 = 0.0815782188,
+                    c8 = 0.4118402518, c9 = 0.4227843370, c10 = 1.0000000000;
+        float temp = 0;
+        temp = temp + c0 * pow(x - 2.0, 10.0) + c1 * pow(x - 2.0, 9.0);
+        temp = temp + c2 * pow(x - 2.0, 8.0) + c3 * pow(x - 2.0, 7.0);
+        temp = temp + c4 * pow(x - 2.0, 6.0) + c5 * pow(x - 2.0, 5.0);
+        temp = temp + c6 * pow(x - 2.0, 4.0) + c7 * pow(x - 2.0, 3.0);
+        temp = temp + c8 * pow(x - 2.0, 2.0) + c9 * (x - 2.0) + c10;
+        return temp;
+    } else if (x > 0 && x <= 1) {
+        return ora_gamma(x + 2) / (x * (x + 1));
+    } else if (x > 1 && x <= 2) {
+        return ora_gamma(x + 1) / x;
+    } else if (x > 3) {
+        int i = 1;
+        float temp = 1;
+        while (((x - i) > 2 && (x - i) <= 3) == 0) {
+            temp = (x - i) * temp;
+            i++;
+        }
+        temp = temp * (x - i);
+        return temp * ora_gamma(x - i);
+    }
+    return 0;
+}
+
+/* BP_GPU::returnWeights, BP_GPU.cu:514-525 */
+void ora_get_weights(ora_net *net, float *const *weights, float *const *bias) {
+    for (int l = 1; l < net->numlayers; l++) {
+        memcpy(weights[l], net->weights[l], (size_t)net->layersizes[l] * net->layersizes[l - 1] * sizeof(float));
+        memcpy(bias[l], net->bias[l], net->layersizes[l] * sizeof(float));
+    }
+}
+
+void ora_set_scalefactor(ora_net *net, const float *alpha) {
+    memcpy(net->scalefactor, alpha, net->layersizes[net->numlayers - 1] * sizeof(float));
+}
+
+const float *ora_tensor(ora_net *net, const char *name, int layer, long *count) {
+    const int L = net->numlayers, D = net->layersizes[L - 1];
+    long c = 0;
+    const float *p = NULL;
+    if (!strcmp(name, "scalefactor")) { p = net->scalefactor; c = D; }
+    else if (!strcmp(name, "out")) { p = net->out; c = (long)net->cap_frames * D; }
+    else if (layer >= 1 && layer < L) {
+        const long N = net->layersizes[layer], K = net->layersizes[layer - 1];
+        if (!strcmp(name, "x")) { p = net->layer_x[layer]; c = net->cap_frames * N; }
+        else if (!strcmp(name, "y")) { p = net->layer_y[layer]; c = net->cap_frames * N; }
+        else if (!strcmp(name, "dedx")) { p = net->layer_dedx[layer]; c = net->cap_frames * N; }
+        else if (!strcmp(name, "dedy")) { p = net->layer_dedy[layer]; c = net->cap_frames * N; }
+        else if (!strcmp(name, "grad_w")) { p = net->layer_ydedx[layer]; c = N * K; }
+        else if (!strcmp(name, "grad_b")) { p = net->layer_sumdedx[layer]; c = N; }
+        else if (!strcmp(name, "delta_w")) { p = net->delta_weights[layer]; c = N * K; }
+        else if (!strcmp(name, "delta_b")) { p = net->delta_bias[layer]; c = N; }
+        else if (!strcmp(name, "weights")) { p = net->weights[layer]; c = N * K; }
+        else if (!strcmp(name, "bias")) { p = net->bias[layer]; c = N; }
+    }
+    if (count) *count = c;
+    return p;
+}

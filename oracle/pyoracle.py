@@ -1,0 +1,190 @@
+"""ctypes binding of the CPU oracle (oracle/libmlggd_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg -- never by the product package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libmlggd_oracle.so")
+_lib = None
+
+_fp = C.POINTER(C.c_float)
+_fpp = C.POINTER(_fp)
+
+
+def build(force=False):
+    if force or not os.path.exists(_LIB) or (
+        os.path.getmtime(_LIB) < os.path.getmtime(os.path.join(_HERE, "mlggd_oracle.c"))
+    ):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB)
+        L.ora_create.restype = C.c_void_p
+        L.ora_create.argtypes = [C.c_int, C.POINTER(C.c_int), C.c_int, C.c_float, C.c_float,
+                                 C.c_float, C.c_float, C.c_int, _fpp, _fpp]
+        L.ora_destroy.argtypes = [C.c_void_p]
+        L.ora_train.restype = C.c_int
+        L.ora_train.argtypes = [C.c_void_p, C.c_int, _fp, _fp]
+        L.ora_train_bunch.argtypes = [C.c_void_p, C.c_int, _fp, _fp]
+        L.ora_forward.argtypes = [C.c_void_p, C.c_int, _fp]
+        L.ora_loss_colsum.argtypes = [C.c_void_p, C.c_int, _fp, _fp]
+        L.ora_loss_grad.argtypes = [C.c_void_p, C.c_int, C.c_int, _fp, _fp]
+        L.ora_backward.argtypes = [C.c_void_p, C.c_int, _fp]
+        L.ora_apply_update.argtypes = [C.c_void_p, C.c_int]
+        L.ora_cv_bunch.argtypes = [C.c_void_p, C.c_int, _fp, _fp]
+        for f in (L.ora_cv_sqerr, L.ora_cv_abserr, L.ora_cv_loglik):
+            f.restype = C.c_float
+            f.argtypes = [C.c_void_p, C.c_int, _fp, _fp]
+        L.ora_gamma.restype = C.c_float
+        L.ora_gamma.argtypes = [C.c_float]
+        L.ora_get_weights.argtypes = [C.c_void_p, _fpp, _fpp]
+        L.ora_set_scalefactor.argtypes = [C.c_void_p, _fp]
+        L.ora_tensor.restype = _fp
+        L.ora_tensor.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_long)]
+        L.ora_num_threads.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _f32(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(_fp)
+
+
+def _ptr_array(arrs):
+    """float*[numlayers] with index 0 unused (NULL), like BP_GPU's float** args."""
+    n = len(arrs) + 1
+    pa = (_fp * n)()
+    for i, a in enumerate(arrs):
+        pa[i + 1] = a.ctypes.data_as(_fp)
+    return pa
+
+
+class OracleNet:
+    """Mirror of the reference's class BP_GPU (BP_GPU.h:45-70) on the CPU oracle."""
+
+    def __init__(self, layersizes, bunchsize, lrate, momentum, weightcost, shapefactor, MLflag,
+                 weights, bias):
+        self.layersizes = [int(x) for x in layersizes]
+        self.L = len(self.layersizes)
+        self.bunchsize = int(bunchsize)
+        self.D = self.layersizes[-1]
+        self._w = [np.ascontiguousarray(w, dtype=np.float32) for w in weights]
+        self._b = [np.ascontiguousarray(b, dtype=np.float32) for b in bias]
+        assert len(self._w) == self.L - 1
+        for l in range(1, self.L):
+            assert self._w[l - 1].shape == (self.layersizes[l - 1], self.layersizes[l])
+        ls = (C.c_int * self.L)(*self.layersizes)
+        self._h = lib().ora_create(self.L, ls, self.bunchsize, lrate, momentum, weightcost,
+                                   shapefactor, int(MLflag), _ptr_array(self._w), _ptr_array(self._b))
+        assert self._h
+
+    def close(self):
+        if self._h:
+            lib().ora_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def train(self, inp, targ):
+        inp, pi = _f32(inp)
+        targ, pt = _f32(targ)
+        return lib().ora_train(self._h, inp.shape[0], pi, pt)
+
+    def train_bunch(self, inp, targ):
+        inp, pi = _f32(inp)
+        targ, pt = _f32(targ)
+        lib().ora_train_bunch(self._h, inp.shape[0], pi, pt)
+
+    # phases (data-parallel contract)
+    def forward(self, inp):
+        inp, pi = _f32(inp)
+        lib().ora_forward(self._h, inp.shape[0], pi)
+
+    def loss_colsum(self, targ):
+        targ, pt = _f32(targ)
+        out = np.zeros(self.D, np.float32)
+        lib().ora_loss_colsum(self._h, targ.shape[0], pt, out.ctypes.data_as(_fp))
+        return out
+
+    def loss_grad(self, targ, n_global, colsum):
+        targ, pt = _f32(targ)
+        cs, pc = _f32(colsum)
+        lib().ora_loss_grad(self._h, targ.shape[0], int(n_global), pt, pc)
+
+    def backward(self, inp):
+        inp, pi = _f32(inp)
+        lib().ora_backward(self._h, inp.shape[0], pi)
+
+    def apply_update(self, n_global):
+        lib().ora_apply_update(self._h, int(n_global))
+
+    def cv_forward(self, inp):
+        inp, pi = _f32(inp)
+        out = np.zeros((inp.shape[0], self.D), np.float32)
+        lib().ora_cv_bunch(self._h, inp.shape[0], pi, out.ctypes.data_as(_fp))
+        return out
+
+    def cv_sqerr(self, inp, targ):
+        inp, pi = _f32(inp)
+        targ, pt = _f32(targ)
+        return float(lib().ora_cv_sqerr(self._h, inp.shape[0], pi, pt))
+
+    def cv_abserr(self, inp, targ):
+        inp, pi = _f32(inp)
+        targ, pt = _f32(targ)
+        return float(lib().ora_cv_abserr(self._h, inp.shape[0], pi, pt))
+
+    def cv_loglik(self, inp, targ):
+        inp, pi = _f32(inp)
+        targ, pt = _f32(targ)
+        return float(lib().ora_cv_loglik(self._h, inp.shape[0], pi, pt))
+
+    def get_weights(self):
+        ws = [np.zeros((self.layersizes[l - 1], self.layersizes[l]), np.float32) for l in range(1, self.L)]
+        bs = [np.zeros(self.layersizes[l], np.float32) for l in range(1, self.L)]
+        lib().ora_get_weights(self._h, _ptr_array(ws), _ptr_array(bs))
+        return ws, bs
+
+    def set_scalefactor(self, alpha):
+        a, pa = _f32(alpha)
+        assert a.shape == (self.D,)
+        lib().ora_set_scalefactor(self._h, pa)
+
+    def tensor(self, name, layer=0, rows=None):
+        cnt = C.c_long(0)
+        p = lib().ora_tensor(self._h, name.encode(), int(layer), C.byref(cnt))
+        if not p:
+            raise KeyError(name)
+        a = np.ctypeslib.as_array(p, shape=(cnt.value,)).copy()
+        if name in ("grad_w", "delta_w", "weights"):
+            return a.reshape(self.layersizes[layer - 1], self.layersizes[layer])
+        if name in ("out",):
+            a = a.reshape(-1, self.D)
+            return a if rows is None else a[:rows]
+        if name in ("x", "y", "dedx", "dedy"):
+            a = a.reshape(-1, self.layersizes[layer])
+            return a if rows is None else a[:rows]
+        return a
+
+
+def gamma(x):
+    return float(lib().ora_gamma(float(x)))
+
+
+def num_threads():
+    return int(lib().ora_num_threads())
