@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""bench.py -- training frames/s of the ML-GGD DNN trainer hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one pass of the hot path (BP_GPU::train_bunch_single, BP_GPU.cu:308-440) over one
+128-frame minibatch per GPU of synthetic 257x11 -> 2048x3 -> 257 data already resident in HBM.
+Prints ONE JSON line (rank 0).  N>1 is data parallel (weak scaling: 128 frames per GPU, RCCL
+all-reduce of the weight gradients inside libmlggd.so); torch.distributed is only used for the
+rendezvous, the barriers and the max-over-ranks of the wall time.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+PKG = "speech-enhancement-based-on-a-maximum-likelihood-criterion_amd"
+
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X fp32 matrix peak, MI355X_MICROARCH.md "Chip-level parameters"
+
+
+def flop_per_frame(ls):
+    P = sum(ls[i] * ls[i + 1] for i in range(len(ls) - 1))
+    return 2 * P + 2 * P + 2 * (P - ls[0] * ls[1])  # fwd + dW + dX (no dX for layer 1)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--loss", choices=["mmse", "ml"], default="mmse",
+                    help="mmse = BASELINE.json configs[1] (MLflag=0, beta=2); ml = configs[2] (MLflag=1, beta=1.2)")
+    ap.add_argument("--bunch", type=int, default=128)
+    ap.add_argument("--hidden", type=int, default=2048)
+    ap.add_argument("--nhid", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+
+    pkg = importlib.import_module(PKG)
+    synth = importlib.import_module(PKG + ".synth")
+    pkg.load()
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    B = args.bunch
+    ls = synth.baseline_layersizes(hidden=args.hidden, nhid=args.nhid)
+    ml, beta = (1, 1.2) if args.loss == "ml" else (0, 2.0)
+    ws, bs = synth.make_weights(ls)  # same weights on every rank
+    nb = min(max(args.steps, args.warmup, 1), 64)  # resident bunches, cycled
+    inp, targ = synth.make_frames(nb * B, 257, 11, seed=synth.DEFAULT_SEED + 1 + rank)
+
+    eng = pkg.BPGpu(synth.DEFAULT_SEED, local_rank, ls, B, 0.1, 0.9, 1e-5, ws, bs, beta, ml)
+    if world > 1:
+        uid = [pkg.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        eng.comm_init(uid[0], world, rank)
+    eng.load_chunk(inp, targ)
+
+    def run_steps(k):
+        done = 0
+        while done < k:
+            m = min(k - done, nb)
+            got = eng.train_resident(0, m * B)
+            assert got == m
+            done += m
+
+    run_steps(args.warmup)
+    eng.sync()
+    dw_layers = 0
+    if not args.no_kernel_timing:
+        eng.profile_select("dw", 0, args.steps * (len(ls) - 1))
+    barrier()
+    t0 = time.perf_counter()
+    run_steps(args.steps)
+    eng.sync()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    roofline = None
+    if not args.no_kernel_timing:
+        us, nlaunch = eng.profile_read()
+        eng.profile_select(None)
+        # the dominant kernel: k_dw (weight-gradient GEMM + fused SGD update), big-tile variant
+        big = [l for l in range(1, len(ls)) if ls[l] % 128 == 0]
+        fl = sum(eng.kernel_work("dw", l)[0] for l in big) / max(len(big), 1)
+        by = sum(eng.kernel_work("dw", l)[1] for l in big) / max(len(big), 1)
+        if nlaunch > 0 and us > 0:
+            ach = fl / (us * 1e-6) / 1e12
+            roofline = {"bound": "mfma", "kernel": "k_dw<2,2,fused> (dW GEMM + momentum/weight-decay update)",
+                        "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                        "mean_launch_us": round(us, 2), "launches_timed": nlaunch,
+                        "algorithmic_flops_per_launch": fl, "algorithmic_bytes_per_launch": by,
+                        "algorithmic_GBps": round(by / (us * 1e-6) / 1e9, 1)}
+
+    frames = args.steps * B * world
+    value = frames / dt
+    fpf = flop_per_frame(ls)
+    out = {
+        "metric": "training frames/sec (128-frame minibatch)",
+        "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 5),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "%s-%s sigmoid DNN, %s, %d-frame minibatch per GPU, synthetic pfile-shaped frames"
+                   % (ls[0], "x".join(str(x) for x in ls[1:]),
+                      "ML-GGD loss (MLflag=1, beta=1.2)" if ml else "MMSE loss (MLflag=0, beta=2)", B),
+                   "layersizes": ls, "bunchsize_per_gpu": B, "global_minibatch": B * world,
+                   "parallelism": "dp%d" % world, "flop_per_frame": fpf},
+        "step_roofline_frac": round(value * fpf / (world * MFMA_F32_PEAK_TFLOPS * 1e12), 4),
+        "roofline": roofline,
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import pyoracle  # CPU oracle = the checker, timed here only as the reported CPU baseline
+        ora = pyoracle.OracleNet(ls, B, 0.1, 0.9, 1e-5, beta, ml, ws, bs)
+        ora.train_bunch(inp[:B], targ[:B])
+        t1 = time.perf_counter()
+        ora.train_bunch(inp[:B], targ[:B])
+        one = time.perf_counter() - t1
+        n = int(min(max(args.cpu_seconds / max(one, 1e-3), 4), min(nb, 200)))
+        t1 = time.perf_counter()
+        for i in range(n):
+            ora.train_bunch(inp[(i % nb) * B:(i % nb + 1) * B], targ[(i % nb) * B:(i % nb + 1) * B])
+        cdt = time.perf_counter() - t1
+        out["cpu_baseline"] = {"value": round(n * B / cdt, 1), "unit": "frames/s", "cores": pyoracle.num_threads(),
+                               "kind": "port", "sample": "%d steps of the same %d-frame minibatches (oracle, OpenMP)"
+                               % (n, B), "gpu_over_cpu": round(value / (n * B / cdt), 1)}
+        ora.close()
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

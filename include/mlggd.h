@@ -1,0 +1,138 @@
+/*
+ * mlggd.h -- C-ABI of the MI355X (gfx950) training engine: the drop-in boundary for the
+ * reference's device engine `class BP_GPU` (Train_code_ML_GGD/BP_GPU.h:45-70), which has
+ * no FFI layer of its own.  Plain pointers and sizes only; every entry point returns an int
+ * status (0 = MLGGD_OK) and mlggd_last_error() gives the message, where the reference
+ * printf()s and exit(0)s (BP_GPU.cu:20,534,578).
+ *
+ * Conventions shared with the reference:
+ *  - host matrices are row-major: in [n_frames][layersizes[0]], targ/out
+ *    [n_frames][layersizes[L-1]], weights[l] [layersizes[l-1]][layersizes[l]];
+ *  - weights[] / bias[] are arrays of numlayers pointers indexed by layer l = 1..L-1
+ *    (slot 0 unused), exactly as BP_GPU's float** arguments (BPtrain.cc:77-78,108);
+ *  - the caller owns all host buffers; the engine copies on entry and owns device memory;
+ *  - calls are synchronous unless stated otherwise and must come from one thread.
+ */
+#ifndef MLGGD_H
+#define MLGGD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MLGGD_MAXLAYER 10          /* BP_GPU.h:6  MAXLAYER */
+#define MLGGD_MAXCACHEFRAME 200000 /* BP_GPU.h:7  MAXCACHEFRAME */
+#define MLGGD_UNIQUE_ID_BYTES 128  /* sizeof(ncclUniqueId) */
+
+enum {
+    MLGGD_OK = 0,
+    MLGGD_ERR_ARG = 1,     /* bad argument / shape */
+    MLGGD_ERR_DEVICE = 2,  /* HIP runtime error (no device, alloc, launch) */
+    MLGGD_ERR_COMM = 3,    /* RCCL error */
+    MLGGD_ERR_STATE = 4    /* call not valid in the engine's current state */
+};
+
+typedef struct mlggd_engine *mlggd_handle;
+
+/* Constructor arguments of BP_GPU (BP_GPU.h:48-49, BP_GPU.cu:9-11), same meaning. */
+typedef struct mlggd_config {
+    int32_t struct_size;     /* = sizeof(mlggd_config), ABI guard */
+    int32_t random_seed;     /* seeds the dropout generator (BP_GPU.cu:59-60) */
+    int32_t device;          /* GPU ordinal, BP_GPU.cu:15-23 (gpu_used=) */
+    int32_t numlayers;       /* 2..MLGGD_MAXLAYER */
+    int32_t layersizes[MLGGD_MAXLAYER];
+    int32_t bunchsize;       /* frames per minibatch on THIS rank */
+    float lrate;
+    float momentum;
+    float weightcost;
+    float shapefactor;       /* beta of the GGD / beta-norm */
+    int32_t MLflag;          /* 1: ML-GGD objective, else beta-norm (BP_GPU.cu:408-424) */
+    int32_t dropoutflag;     /* BP_GPU.cu:344-355,484-501 */
+    float visible_omit;
+    float hid_omit;
+    int32_t max_cache_frames; /* rows of the resident chunk buffers; 0 -> MLGGD_MAXCACHEFRAME */
+    int32_t reserved[7];
+} mlggd_config;
+
+/* ---- lifetime: BP_GPU::BP_GPU / ~BP_GPU (BP_GPU.cu:9-150) ---- */
+int mlggd_create(const mlggd_config *cfg, const float *const *weights, const float *const *bias,
+                 mlggd_handle *out);
+int mlggd_destroy(mlggd_handle h);
+const char *mlggd_last_error(void);
+int mlggd_device_count(int *count); /* cudaGetDeviceCount, BP_GPU.cu:15 */
+
+/* ---- training: BP_GPU::train (BP_GPU.cu:152-185) ----
+ * Uploads the chunk, runs train_bunch_single (BP_GPU.cu:308-440) on every FULL bunch and
+ * skips the trailing partial bunch, returns after the last step has completed.
+ * *bunches_trained (optional) receives the number of steps run. */
+int mlggd_train_chunk(mlggd_handle h, int n_frames, const float *in, const float *targ,
+                      int *bunches_trained);
+
+/* The same, split so a benchmark can time steps on HBM-resident data:
+ * mlggd_load_chunk = the two todev_vf_vf calls (BP_GPU.cu:163-164);
+ * mlggd_train_resident = the bunch loop (BP_GPU.cu:170-184) over frames
+ * [first_frame, first_frame + n_frames) of the resident chunk; asynchronous --
+ * mlggd_sync() waits for completion. */
+int mlggd_load_chunk(mlggd_handle h, int n_frames, const float *in, const float *targ);
+int mlggd_train_resident(mlggd_handle h, int first_frame, int n_frames, int *bunches_trained);
+int mlggd_sync(mlggd_handle h);
+
+/* ---- cross-validation: BP_GPU::CrossValid / CrossValiddB / CrossValid2
+ * (BP_GPU.cu:187-306) over cv_bunch_single (BP_GPU.cu:442-512).  Each returns the chunk's
+ * sum exactly as the reference accumulates it (host fp32 scalar, frame-major order):
+ * sqerr = sum (o-t)^2 ; abserr = sum |o-t| / D ; loglik = GGD log-likelihood with the
+ * alpha of the last training minibatch. */
+int mlggd_cv_sqerr(mlggd_handle h, int n_frames, const float *in, const float *targ, float *out);
+int mlggd_cv_abserr(mlggd_handle h, int n_frames, const float *in, const float *targ, float *out);
+int mlggd_cv_loglik(mlggd_handle h, int n_frames, const float *in, const float *targ, float *out);
+/* All three from ONE forward pass (same accumulation order; loglik only if MLflag==1). */
+int mlggd_cv_all(mlggd_handle h, int n_frames, const float *in, const float *targ,
+                 float *sqerr, float *abserr, float *loglik);
+/* cv_bunch_single over a whole chunk: out[n_frames][D] network outputs (forward only). */
+int mlggd_forward(mlggd_handle h, int n_frames, const float *in, float *out);
+
+/* ---- state: BP_GPU::returnWeights (BP_GPU.cu:514-525) and dev.scalefactor (:287) ---- */
+int mlggd_get_weights(mlggd_handle h, float *const *weights, float *const *bias);
+int mlggd_set_weights(mlggd_handle h, const float *const *weights, const float *const *bias);
+int mlggd_get_scalefactor(mlggd_handle h, float *alpha /* [D] */);
+int mlggd_set_scalefactor(mlggd_handle h, const float *alpha /* [D] */);
+int mlggd_set_lrate(mlggd_handle h, float lrate);
+float mlggd_gamma(float x); /* BP_GPU::Gamma, BP_GPU.cu:593-640 */
+
+/* Copies an internal tensor of the LAST step to the host in the reference's row-major
+ * layout (parity tests).  name: "out" "y" "dedx" [bunchsize][units(layer)];
+ * "delta_w" "weights" [K][N]; "delta_b" "bias" [N]; "scalefactor" [D].
+ * count = capacity of dst in floats; fails if too small. */
+int mlggd_debug_tensor(mlggd_handle h, const char *name, int layer, float *dst, size_t count);
+
+/* ---- data parallel over the GPUs of one node (new work): one process per
+ * GPU; rank r trains rows [r*bunchsize,(r+1)*bunchsize) of every global minibatch of
+ * world*bunchsize frames.  Exchanges per step (RCCL, fp32 sum): the per-dimension
+ * sum |e|^beta (ML only) and the weight/bias gradients; every 1/n_frames factor uses the
+ * GLOBAL minibatch size, so the run equals a single-device run with bunchsize =
+ * world*bunchsize.  rank 0 fills a unique id, the caller broadcasts it out of band. */
+int mlggd_comm_unique_id(void *id /* MLGGD_UNIQUE_ID_BYTES */);
+int mlggd_comm_init(mlggd_handle h, const void *id, int world_size, int rank);
+
+/* Per-step device time of the last mlggd_train_resident call, measured with HIP events
+ * on the engine's stream: total ms over `steps` steps. */
+int mlggd_last_train_ms(mlggd_handle h, float *ms, int *steps);
+
+/* Kernel-class timing INSIDE a timed mlggd_train_resident region (bench.py's roofline
+ * object): mlggd_profile_select brackets every launch of the named class ("transpose" "fwd"
+ * "loss" "dx" "dw" "bias" "update"; layer 0 = all layers) with HIP events on the engine's
+ * stream, up to max_launches; NULL/"" switches it off.  mlggd_profile_read syncs and returns
+ * the mean launch duration in microseconds and the number of launches seen.
+ * mlggd_kernel_work gives the algorithmic FLOPs / bytes of ONE launch of (class, layer)
+ * (layer 0 = summed over layers), the figures DESIGN.md states per kernel. */
+int mlggd_profile_select(mlggd_handle h, const char *kernel_class, int layer, int max_launches);
+int mlggd_profile_read(mlggd_handle h, float *mean_usec, int *launches);
+int mlggd_kernel_work(mlggd_handle h, const char *kernel_class, int layer, double *flops, double *bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MLGGD_H */

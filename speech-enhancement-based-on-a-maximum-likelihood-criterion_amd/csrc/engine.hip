@@ -1,0 +1,885 @@
+// engine.hip -- host side of the MI355X training engine behind the C-ABI of include/mlggd.h.
+//
+// Mirrors what the reference's class BP_GPU does on the host (Train_code_ML_GGD/BP_GPU.cu):
+// device workspace (BP_WorkSpace, BP_GPU.h:17-43), chunk upload, the bunch loop, CV metric
+// accumulation and weight read-back -- re-designed for one HIP stream of fused gfx950 kernels
+// (kernels.hip.h) instead of ~50 launches + cuBLAS on two racing streams.
+#include <hip/hip_runtime.h>
+
+#include <dlfcn.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/mlggd.h"
+#include "kernels.hip.h"
+
+// ------------------------------------------------------------------ errors
+static thread_local char g_err[1024] = "";
+static int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess)                                                                          \
+            return fail(MLGGD_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+#define CHK(expr)                 \
+    do {                          \
+        int _rc = (expr);         \
+        if (_rc != MLGGD_OK) return _rc; \
+    } while (0)
+
+static inline int ceil32(int x) { return (x + 31) & ~31; }
+
+// ------------------------------------------------------------------ RCCL (loaded on demand)
+// Only the data-parallel path needs RCCL; it is dlopen'ed at mlggd_comm_init so a single-GPU
+// process never maps it.  Types per rccl.h (ncclUniqueId = 128 opaque bytes, ncclFloat = 7,
+// ncclSum = 0).
+struct RcclUniqueId {
+    char internal[128];
+};
+typedef void *RcclComm;
+struct RcclApi {
+    void *lib = nullptr;
+    int (*GetUniqueId)(RcclUniqueId *) = nullptr;
+    int (*CommInitRank)(RcclComm *, int, RcclUniqueId, int) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, RcclComm, hipStream_t) = nullptr;
+    int (*CommDestroy)(RcclComm) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+};
+static RcclApi g_rccl;
+static int rccl_load() {
+    if (g_rccl.lib) return MLGGD_OK;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *lib = nullptr;
+    for (const char *n : names) {
+        lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (lib) break;
+    }
+    if (!lib) return fail(MLGGD_ERR_COMM, "cannot dlopen librccl: %s", dlerror());
+    g_rccl.GetUniqueId = (int (*)(RcclUniqueId *))dlsym(lib, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (int (*)(RcclComm *, int, RcclUniqueId, int))dlsym(lib, "ncclCommInitRank");
+    g_rccl.AllReduce =
+        (int (*)(const void *, void *, size_t, int, int, RcclComm, hipStream_t))dlsym(lib, "ncclAllReduce");
+    g_rccl.CommDestroy = (int (*)(RcclComm))dlsym(lib, "ncclCommDestroy");
+    g_rccl.GetErrorString = (const char *(*)(int))dlsym(lib, "ncclGetErrorString");
+    g_rccl.GroupStart = (int (*)())dlsym(lib, "ncclGroupStart");
+    g_rccl.GroupEnd = (int (*)())dlsym(lib, "ncclGroupEnd");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy)
+        return fail(MLGGD_ERR_COMM, "librccl is missing required symbols");
+    g_rccl.lib = lib;
+    return MLGGD_OK;
+}
+#define NCCLCHK(expr)                                                                              \
+    do {                                                                                           \
+        int _r = (expr);                                                                           \
+        if (_r != 0)                                                                               \
+            return fail(MLGGD_ERR_COMM, "%s failed: %s", #expr,                                    \
+                        g_rccl.GetErrorString ? g_rccl.GetErrorString(_r) : "rccl error");          \
+    } while (0)
+
+// ------------------------------------------------------------------ engine state
+enum KernelClass { KC_TRANSPOSE = 0, KC_FWD, KC_LOSS, KC_DX, KC_DW, KC_DW_SMALL, KC_BIAS, KC_UPDATE, KC_COUNT };
+static const char *kKernelClassName[KC_COUNT] = {"transpose", "fwd", "loss", "dx", "dw", "dw_small", "bias", "update"};
+
+struct mlggd_engine {
+    mlggd_config cfg;
+    int L = 0;
+    int ls[MLGGD_MAXLAYER] = {0};   // true units
+    int lsp[MLGGD_MAXLAYER] = {0};  // padded to 32
+    int B = 0, Bp = 0, D = 0, Dp = 0, K0 = 0;
+    int device = 0;
+    hipStream_t stream = nullptr, comm_stream = nullptr;
+
+    float *W[MLGGD_MAXLAYER] = {0}, *dW[MLGGD_MAXLAYER] = {0};
+    float *bias[MLGGD_MAXLAYER] = {0}, *dbias[MLGGD_MAXLAYER] = {0};
+    float *G[MLGGD_MAXLAYER] = {0}, *gb[MLGGD_MAXLAYER] = {0};
+    float *gb_all = nullptr;
+    size_t gb_all_count = 0;
+    float *Yt[MLGGD_MAXLAYER] = {0}, *Y[MLGGD_MAXLAYER] = {0};
+    float *dEdXt[MLGGD_MAXLAYER] = {0}, *dEdX[MLGGD_MAXLAYER] = {0};
+    float *slab = nullptr, *outT = nullptr, *eT = nullptr, *colsum = nullptr, *scalefactor = nullptr;
+    int S_out = 1;
+    float *chunk_in = nullptr, *chunk_targ = nullptr, *chunk_out = nullptr;
+    size_t chunk_cap = 0, out_cap = 0;
+    int chunk_frames = 0;
+    unsigned step_counter = 0;
+
+    // data parallel
+    int world = 1, rank = 0;
+    RcclComm comm = nullptr;
+    hipEvent_t ev_grad[MLGGD_MAXLAYER] = {0}, ev_red[MLGGD_MAXLAYER] = {0}, ev_bias = nullptr, ev_bias_red = nullptr;
+
+    // timing
+    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
+    int last_steps = 0;
+    bool timing_valid = false;
+    // per-kernel-class profiling
+    int prof_class = -1, prof_layer = 0;
+    std::vector<hipEvent_t> prof_ev;
+    size_t prof_used = 0;
+    double prof_flops = 0, prof_bytes = 0;
+
+    std::vector<void *> allocs;
+};
+
+static int dev_alloc(mlggd_engine *e, float **p, size_t count) {
+    // +64 floats of slack; zero-filled like the reference's devnew_vf (BP_GPU.cu:528-543)
+    const size_t bytes = (count + 64) * sizeof(float);
+    HIPCHK(hipMalloc((void **)p, bytes));
+    HIPCHK(hipMemset(*p, 0, bytes));
+    e->allocs.push_back(*p);
+    return MLGGD_OK;
+}
+
+static int upload_padded(float *dst, int Np, const float *src, int K, int N, hipStream_t st) {
+    // [K][N] compact -> [Kp][Np] padded rows
+    HIPCHK(hipMemcpy2DAsync(dst, (size_t)Np * 4, src, (size_t)N * 4, (size_t)N * 4, K, hipMemcpyHostToDevice, st));
+    return MLGGD_OK;
+}
+static int download_padded(float *dst, const float *src, int Np, int K, int N, hipStream_t st) {
+    HIPCHK(hipMemcpy2DAsync(dst, (size_t)N * 4, src, (size_t)Np * 4, (size_t)N * 4, K, hipMemcpyDeviceToHost, st));
+    return MLGGD_OK;
+}
+
+// ------------------------------------------------------------------ kernel launch plan
+struct ProfScope {
+    mlggd_engine *e;
+    bool on;
+    ProfScope(mlggd_engine *eng, int cls, int layer) : e(eng), on(false) {
+        if (e->prof_class == cls && (e->prof_layer == 0 || e->prof_layer == layer) &&
+            e->prof_used + 2 <= e->prof_ev.size()) {
+            on = true;
+            hipEventRecord(e->prof_ev[e->prof_used], e->stream);
+        }
+    }
+    ~ProfScope() {
+        if (on) {
+            hipEventRecord(e->prof_ev[e->prof_used + 1], e->stream);
+            e->prof_used += 2;
+        }
+    }
+};
+
+static int launch_check(const char *what) {
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return fail(MLGGD_ERR_DEVICE, "launch of %s failed: %s", what, hipGetErrorString(err));
+    return MLGGD_OK;
+}
+
+static int run_transpose(mlggd_engine *e, const float *in, int frames) {
+    ProfScope ps(e, KC_TRANSPOSE, 0);
+    const int b_tiles = e->Bp / 32, k_tiles = e->lsp[0] / 32;
+    hipLaunchKernelGGL(k_transpose_in, dim3(k_tiles * b_tiles), dim3(256), 0, e->stream, in, e->K0, frames, e->K0,
+                       e->Yt[0], e->Bp, b_tiles);
+    return launch_check("k_transpose_in");
+}
+
+static int run_dropout(mlggd_engine *e, int layer, const float *chunk_rows) {
+    // BP_GPU.cu:344-355: visible_omit on the input, hid_omit on hidden activations
+    const float p = (layer == 0) ? e->cfg.visible_omit : e->cfg.hid_omit;
+    const size_t n = (size_t)e->lsp[layer] * e->Bp;
+    float *rows = (layer == 0) ? const_cast<float *>(chunk_rows) : e->Y[layer];
+    const int ld = (layer == 0) ? e->K0 : e->lsp[layer];
+    hipLaunchKernelGGL(k_dropout, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, e->Yt[layer], rows,
+                       e->ls[layer], e->lsp[layer], ld, e->B, e->Bp, p, (unsigned)e->cfg.random_seed,
+                       e->step_counter * 16u + (unsigned)layer);
+    return launch_check("k_dropout");
+}
+
+static int run_forward(mlggd_engine *e, const float *in_rows, int frames, bool training) {
+    CHK(run_transpose(e, in_rows, frames));
+    const int b_tiles = e->Bp / 32;
+    const bool drop = training && e->cfg.dropoutflag == 1;
+    const bool cvscale = !training && e->cfg.dropoutflag == 1;
+    if (drop) CHK(run_dropout(e, 0, in_rows));
+    for (int l = 1; l < e->L; l++) {
+        const int Kp = e->lsp[l - 1], Np = e->lsp[l], n_tiles = Np / 32;
+        if (cvscale) {  // DevWeightMultiP before the GEMM, BP_GPU.cu:484-489
+            const float keep = 1.0f - ((l == 1) ? e->cfg.visible_omit : e->cfg.hid_omit);
+            hipLaunchKernelGGL(k_scale, dim3(1024), dim3(256), 0, e->stream, e->W[l], (size_t)Kp * Np, keep);
+        }
+        {
+            ProfScope ps(e, KC_FWD, l);
+            if (l != e->L - 1) {
+                hipLaunchKernelGGL(k_fwd<FWD_SIGMOID>, dim3(n_tiles * b_tiles), dim3(256), 0, e->stream, e->W[l],
+                                   e->Yt[l - 1], e->bias[l], e->Yt[l], e->Y[l], (float *)nullptr, Kp, Np, e->Bp,
+                                   e->ls[l], n_tiles, b_tiles, 1);
+            } else {
+                hipLaunchKernelGGL(k_fwd<FWD_SLAB>, dim3(n_tiles * b_tiles * e->S_out), dim3(256), 0, e->stream,
+                                   e->W[l], e->Yt[l - 1], e->bias[l], (float *)nullptr, (float *)nullptr, e->slab, Kp,
+                                   Np, e->Bp, e->ls[l], n_tiles, b_tiles, e->S_out);
+            }
+        }
+        CHK(launch_check("k_fwd"));
+        if (cvscale) {  // BP_GPU.cu:496-501
+            const float keep = 1.0f - ((l == 1) ? e->cfg.visible_omit : e->cfg.hid_omit);
+            hipLaunchKernelGGL(k_scale, dim3(1024), dim3(256), 0, e->stream, e->W[l], (size_t)Kp * Np, 1.0f / keep);
+        }
+        if (drop && l != e->L - 1) CHK(run_dropout(e, l, nullptr));
+    }
+    return MLGGD_OK;
+}
+
+template <int TM, int TN>
+static void launch_dw(mlggd_engine *e, int l, const float *in_rows, bool fused, float nf) {
+    const int Kp = e->lsp[l - 1], Np = e->lsp[l];
+    const int k_wg = (Kp + 64 * TM - 1) / (64 * TM), n_wg = (Np + 64 * TN - 1) / (64 * TN);
+    const float *A = (l == 1) ? in_rows : e->Y[l - 1];
+    const int ldA = (l == 1) ? e->K0 : Kp;
+    if (fused)
+        hipLaunchKernelGGL((k_dw<TM, TN, true>), dim3(k_wg * n_wg), dim3(256), 0, e->stream, A, ldA, ldA, e->dEdX[l],
+                           e->W[l], e->dW[l], (float *)nullptr, e->ls[l - 1], e->ls[l], Np, e->Bp, n_wg, nf,
+                           e->cfg.momentum, e->cfg.lrate, e->cfg.weightcost);
+    else
+        hipLaunchKernelGGL((k_dw<TM, TN, false>), dim3(k_wg * n_wg), dim3(256), 0, e->stream, A, ldA, ldA, e->dEdX[l],
+                           e->W[l], e->dW[l], e->G[l], e->ls[l - 1], e->ls[l], Np, e->Bp, n_wg, nf, e->cfg.momentum,
+                           e->cfg.lrate, e->cfg.weightcost);
+}
+
+static BiasJobs make_bias_jobs(mlggd_engine *e) {
+    BiasJobs jobs;
+    memset(&jobs, 0, sizeof(jobs));
+    int first = 0, nj = 0;
+    for (int l = e->L - 1; l >= 1; l--) {
+        BiasJob &j = jobs.job[nj++];
+        j.dEdX = e->dEdX[l];
+        j.bias = e->bias[l];
+        j.dbias = e->dbias[l];
+        j.gb = e->gb[l];
+        j.N = e->ls[l];
+        j.Np = e->lsp[l];
+        j.first = first;
+        first += e->lsp[l];
+    }
+    jobs.njobs = nj;
+    jobs.total = first;
+    return jobs;
+}
+
+// One SGD step on `frames` (= bunchsize) resident frames: BP_GPU::train_bunch_single,
+// BP_GPU.cu:308-440.
+static int run_step(mlggd_engine *e, const float *in_rows, const float *targ_rows) {
+    const int L = e->L, B = e->B, Bp = e->Bp, b_tiles = Bp / 32;
+    const bool dp = e->world > 1;
+    const int n_global = B * e->world;
+    const float nf = (float)n_global;
+    const float inv_n = 1.0f / n_global;  // DevVecMulNum(..., 1.0f/n_frames, ...), BP_GPU.cu:409,423
+    const int ML = e->cfg.MLflag;
+
+    CHK(run_forward(e, in_rows, B, true));
+    {
+        ProfScope ps(e, KC_LOSS, 0);
+        hipLaunchKernelGGL(k_loss_err, dim3(e->Dp / 32), dim3(256), (size_t)32 * (Bp + 1) * sizeof(float), e->stream,
+                           e->slab, e->S_out, e->bias[L - 1], targ_rows, B, e->D, e->Dp, Bp, e->cfg.shapefactor,
+                           ML == 1 ? 1 : 0, e->outT, e->eT, e->colsum);
+        CHK(launch_check("k_loss_err"));
+        if (dp && ML == 1)
+            NCCLCHK(g_rccl.AllReduce(e->colsum, e->colsum, (size_t)e->Dp, 7, 0, e->comm, e->stream));
+        hipLaunchKernelGGL(k_loss_grad, dim3((e->Dp / 32) * b_tiles), dim3(256), 0, e->stream, e->eT, e->colsum, B,
+                           e->D, e->Dp, Bp, e->cfg.shapefactor, ML, nf, inv_n, e->scalefactor, e->dEdXt[L - 1],
+                           e->dEdX[L - 1], b_tiles);
+        CHK(launch_check("k_loss_grad"));
+    }
+    for (int l = L - 1; l >= 1; l--) {
+        const int Kp = e->lsp[l - 1], Np = e->lsp[l];
+        if (l != 1) {
+            ProfScope ps(e, KC_DX, l);
+            hipLaunchKernelGGL(k_dx, dim3((Kp / 32) * b_tiles), dim3(256), 0, e->stream, e->W[l], e->dEdXt[l],
+                               e->Yt[l - 1], e->dEdXt[l - 1], e->dEdX[l - 1], Kp, Np, Bp, Kp / 32, b_tiles);
+            CHK(launch_check("k_dx"));
+        }
+        {
+            const long tiles128 = (long)((Kp + 127) / 128) * ((Np + 127) / 128);
+            const bool big = tiles128 >= 192 && Np % 128 == 0;
+            ProfScope ps(e, big ? KC_DW : KC_DW_SMALL, l);
+            if (big)
+                launch_dw<2, 2>(e, l, in_rows, !dp, nf);
+            else
+                launch_dw<1, 1>(e, l, in_rows, !dp, nf);
+            CHK(launch_check("k_dw"));
+        }
+        if (dp) {
+            HIPCHK(hipEventRecord(e->ev_grad[l], e->stream));
+            HIPCHK(hipStreamWaitEvent(e->comm_stream, e->ev_grad[l], 0));
+            NCCLCHK(g_rccl.AllReduce(e->G[l], e->G[l], (size_t)Kp * Np, 7, 0, e->comm, e->comm_stream));
+            HIPCHK(hipEventRecord(e->ev_red[l], e->comm_stream));
+        }
+    }
+    {
+        ProfScope ps(e, KC_BIAS, 0);
+        BiasJobs jobs = make_bias_jobs(e);
+        if (!dp) {
+            hipLaunchKernelGGL(k_bias<true>, dim3((jobs.total + 255) / 256), dim3(256), 0, e->stream, jobs, B, nf,
+                               e->cfg.momentum, e->cfg.lrate);
+        } else {
+            hipLaunchKernelGGL(k_bias<false>, dim3((jobs.total + 255) / 256), dim3(256), 0, e->stream, jobs, B, nf,
+                               e->cfg.momentum, e->cfg.lrate);
+        }
+        CHK(launch_check("k_bias"));
+    }
+    if (dp) {
+        HIPCHK(hipEventRecord(e->ev_bias, e->stream));
+        HIPCHK(hipStreamWaitEvent(e->comm_stream, e->ev_bias, 0));
+        NCCLCHK(g_rccl.AllReduce(e->gb_all, e->gb_all, e->gb_all_count, 7, 0, e->comm, e->comm_stream));
+        HIPCHK(hipEventRecord(e->ev_bias_red, e->comm_stream));
+        for (int l = L - 1; l >= 1; l--) {
+            HIPCHK(hipStreamWaitEvent(e->stream, e->ev_red[l], 0));
+            ProfScope ps(e, KC_UPDATE, l);
+            const size_t n4 = (size_t)e->lsp[l - 1] * e->lsp[l] / 4;
+            hipLaunchKernelGGL(k_apply_update, dim3(2048), dim3(256), 0, e->stream, e->W[l], e->dW[l], e->G[l], n4, nf,
+                               e->cfg.momentum, e->cfg.lrate, e->cfg.weightcost);
+            CHK(launch_check("k_apply_update"));
+        }
+        HIPCHK(hipStreamWaitEvent(e->stream, e->ev_bias_red, 0));
+        BiasJobs jobs = make_bias_jobs(e);
+        hipLaunchKernelGGL(k_bias_apply, dim3((jobs.total + 255) / 256), dim3(256), 0, e->stream, jobs, nf,
+                           e->cfg.momentum, e->cfg.lrate);
+        CHK(launch_check("k_bias_apply"));
+    }
+    e->step_counter++;
+    return MLGGD_OK;
+}
+
+// ------------------------------------------------------------------ C-ABI
+extern "C" {
+
+const char *mlggd_last_error(void) { return g_err; }
+
+int mlggd_device_count(int *count) {
+    if (!count) return fail(MLGGD_ERR_ARG, "count is NULL");
+    HIPCHK(hipGetDeviceCount(count));
+    return MLGGD_OK;
+}
+
+int mlggd_create(const mlggd_config *cfg, const float *const *weights, const float *const *bias, mlggd_handle *out) {
+    if (!cfg || !weights || !bias || !out) return fail(MLGGD_ERR_ARG, "NULL argument");
+    if (cfg->struct_size != (int32_t)sizeof(mlggd_config))
+        return fail(MLGGD_ERR_ARG, "mlggd_config.struct_size %d != %d", cfg->struct_size, (int)sizeof(mlggd_config));
+    if (cfg->numlayers < 2 || cfg->numlayers > MLGGD_MAXLAYER)
+        return fail(MLGGD_ERR_ARG, "numlayers %d not in 2..%d", cfg->numlayers, MLGGD_MAXLAYER);
+    if (cfg->bunchsize < 1) return fail(MLGGD_ERR_ARG, "bunchsize %d < 1", cfg->bunchsize);
+    for (int i = 0; i < cfg->numlayers; i++)
+        if (cfg->layersizes[i] < 1) return fail(MLGGD_ERR_ARG, "layersizes[%d] = %d", i, cfg->layersizes[i]);
+    if ((size_t)32 * (ceil32(cfg->bunchsize) + 1) * sizeof(float) > 150 * 1024)
+        return fail(MLGGD_ERR_ARG, "bunchsize %d too large for the loss kernel's LDS tile (max 1152)", cfg->bunchsize);
+    int ndev = 0;
+    hipError_t de = hipGetDeviceCount(&ndev);
+    if (de != hipSuccess || ndev < 1)
+        return fail(MLGGD_ERR_DEVICE, "no HIP device available (%s)", de == hipSuccess ? "count 0" : hipGetErrorString(de));
+    // BP_GPU.cu:17-21 "GPU Num %d Not In Range"
+    if (cfg->device < 0 || cfg->device >= ndev)
+        return fail(MLGGD_ERR_ARG, "GPU Num %d Not In Range %d-%d", cfg->device, 0, ndev - 1);
+
+    mlggd_engine *e = new mlggd_engine();
+    e->cfg = *cfg;
+    e->L = cfg->numlayers;
+    e->device = cfg->device;
+    for (int i = 0; i < e->L; i++) {
+        e->ls[i] = cfg->layersizes[i];
+        e->lsp[i] = ceil32(cfg->layersizes[i]);
+    }
+    e->B = cfg->bunchsize;
+    e->Bp = ceil32(e->B);
+    e->K0 = e->ls[0];
+    e->D = e->ls[e->L - 1];
+    e->Dp = e->lsp[e->L - 1];
+    *out = e;  // so the caller can destroy on failure
+
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreate(&e->ev_t0));
+    HIPCHK(hipEventCreate(&e->ev_t1));
+
+    const int L = e->L, Bp = e->Bp;
+    CHK(dev_alloc(e, &e->Yt[0], (size_t)e->lsp[0] * Bp));
+    for (int l = 1; l < L; l++) {
+        const size_t wsz = (size_t)e->lsp[l - 1] * e->lsp[l];
+        CHK(dev_alloc(e, &e->W[l], wsz));
+        CHK(dev_alloc(e, &e->dW[l], wsz));
+        CHK(dev_alloc(e, &e->bias[l], e->lsp[l]));
+        CHK(dev_alloc(e, &e->dbias[l], e->lsp[l]));
+        const size_t asz = (size_t)e->lsp[l] * Bp;
+        if (l != L - 1) {
+            CHK(dev_alloc(e, &e->Yt[l], asz));
+            CHK(dev_alloc(e, &e->Y[l], asz));
+        }
+        CHK(dev_alloc(e, &e->dEdXt[l], asz));
+        CHK(dev_alloc(e, &e->dEdX[l], asz));
+    }
+    // output-layer GEMM: split K across workgroups so the small N still fills the chip
+    {
+        const int tiles = (e->Dp / 32) * (Bp / 32);
+        const int pairs = e->lsp[L - 2] / 2;
+        int S = (256 + tiles - 1) / tiles;
+        if (S > pairs / 16) S = pairs / 16;  // >= 4 k-pairs per wave
+        if (S < 1) S = 1;
+        if (S > 32) S = 32;
+        e->S_out = S;
+    }
+    CHK(dev_alloc(e, &e->slab, (size_t)e->S_out * e->Dp * Bp));
+    CHK(dev_alloc(e, &e->outT, (size_t)e->Dp * Bp));
+    CHK(dev_alloc(e, &e->eT, (size_t)e->Dp * Bp));
+    CHK(dev_alloc(e, &e->colsum, e->Dp));
+    CHK(dev_alloc(e, &e->scalefactor, e->Dp));
+
+    const int rc = mlggd_set_weights(e, weights, bias);
+    if (rc != MLGGD_OK) return rc;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return MLGGD_OK;
+}
+
+int mlggd_destroy(mlggd_handle e) {
+    if (!e) return MLGGD_OK;
+    hipSetDevice(e->device);
+    if (e->stream) hipStreamSynchronize(e->stream);
+    if (e->comm_stream) hipStreamSynchronize(e->comm_stream);
+    if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
+    for (void *p : e->allocs) hipFree(p);
+    if (e->chunk_in) hipFree(e->chunk_in);
+    if (e->chunk_targ) hipFree(e->chunk_targ);
+    if (e->chunk_out) hipFree(e->chunk_out);
+    for (hipEvent_t ev : e->prof_ev) hipEventDestroy(ev);
+    for (int l = 0; l < MLGGD_MAXLAYER; l++) {
+        if (e->ev_grad[l]) hipEventDestroy(e->ev_grad[l]);
+        if (e->ev_red[l]) hipEventDestroy(e->ev_red[l]);
+    }
+    if (e->ev_bias) hipEventDestroy(e->ev_bias);
+    if (e->ev_bias_red) hipEventDestroy(e->ev_bias_red);
+    if (e->ev_t0) hipEventDestroy(e->ev_t0);
+    if (e->ev_t1) hipEventDestroy(e->ev_t1);
+    if (e->comm_stream) hipStreamDestroy(e->comm_stream);
+    if (e->stream) hipStreamDestroy(e->stream);
+    delete e;
+    return MLGGD_OK;
+}
+
+int mlggd_set_weights(mlggd_handle e, const float *const *weights, const float *const *bias) {
+    if (!e || !weights || !bias) return fail(MLGGD_ERR_ARG, "NULL argument");
+    HIPCHK(hipSetDevice(e->device));
+    for (int l = 1; l < e->L; l++) {
+        if (!weights[l] || !bias[l]) return fail(MLGGD_ERR_ARG, "weights[%d] or bias[%d] is NULL", l, l);
+        CHK(upload_padded(e->W[l], e->lsp[l], weights[l], e->ls[l - 1], e->ls[l], e->stream));  // BP_GPU.cu:106
+        HIPCHK(hipMemcpyAsync(e->bias[l], bias[l], (size_t)e->ls[l] * 4, hipMemcpyHostToDevice, e->stream));  // :107
+    }
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return MLGGD_OK;
+}
+
+int mlggd_get_weights(mlggd_handle e, float *const *weights, float *const *bias) {
+    if (!e || !weights || !bias) return fail(MLGGD_ERR_ARG, "NULL argument");
+    HIPCHK(hipSetDevice(e->device));
+    for (int l = 1; l < e->L; l++) {
+        if (!weights[l] || !bias[l]) return fail(MLGGD_ERR_ARG, "weights[%d] or bias[%d] is NULL", l, l);
+        CHK(download_padded(weights[l], e->W[l], e->lsp[l], e->ls[l - 1], e->ls[l], e->stream));  // BP_GPU.cu:522
+        HIPCHK(hipMemcpyAsync(bias[l], e->bias[l], (size_t)e->ls[l] * 4, hipMemcpyDeviceToHost, e->stream));  // :523
+    }
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return MLGGD_OK;
+}
+
+int mlggd_get_scalefactor(mlggd_handle e, float *alpha) {
+    if (!e || !alpha) return fail(MLGGD_ERR_ARG, "NULL argument");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipMemcpyAsync(alpha, e->scalefactor, (size_t)e->D * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return MLGGD_OK;
+}
+
+int mlggd_set_scalefactor(mlggd_handle e, const float *alpha) {
+    if (!e || !alpha) return fail(MLGGD_ERR_ARG, "NULL argument");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipMemcpyAsync(e->scalefactor, alpha, (size_t)e->D * 4, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return MLGGD_OK;
+}
+
+int mlggd_set_lrate(mlggd_handle e, float lrate) {
+    if (!e) return fail(MLGGD_ERR_ARG, "NULL handle");
+    e->cfg.lrate = lrate;
+    return MLGGD_OK;
+}
+
+static int ensure_chunk(mlggd_engine *e, int n_frames) {
+    const size_t need = (size_t)n_frames + e->Bp + 32;  // slack rows: padded tiles may read past the last frame
+    if (need <= e->chunk_cap) return MLGGD_OK;
+    if (e->chunk_in) hipFree(e->chunk_in);
+    if (e->chunk_targ) hipFree(e->chunk_targ);
+    e->chunk_in = e->chunk_targ = nullptr;
+    e->chunk_cap = 0;
+    HIPCHK(hipMalloc((void **)&e->chunk_in, need * e->K0 * sizeof(float)));
+    HIPCHK(hipMalloc((void **)&e->chunk_targ, need * e->D * sizeof(float)));
+    HIPCHK(hipMemsetAsync(e->chunk_in, 0, need * e->K0 * sizeof(float), e->stream));
+    HIPCHK(hipMemsetAsync(e->chunk_targ, 0, need * e->D * sizeof(float), e->stream));
+    e->chunk_cap = need;
+    return MLGGD_OK;
+}
+
+static int check_frames(mlggd_engine *e, int n_frames) {
+    if (n_frames < 0) return fail(MLGGD_ERR_ARG, "n_frames %d < 0", n_frames);
+    const int cap = e->cfg.max_cache_frames > 0 ? e->cfg.max_cache_frames : MLGGD_MAXCACHEFRAME;
+    if (n_frames > cap) return fail(MLGGD_ERR_ARG, "n_frames %d exceeds the chunk capacity %d", n_frames, cap);
+    return MLGGD_OK;
+}
+
+int mlggd_load_chunk(mlggd_handle e, int n_frames, const float *in, const float *targ) {
+    if (!e) return fail(MLGGD_ERR_ARG, "NULL handle");
+    CHK(check_frames(e, n_frames));
+    if (n_frames > 0 && !in) return fail(MLGGD_ERR_ARG, "in is NULL");
+    HIPCHK(hipSetDevice(e->device));
+    CHK(ensure_chunk(e, n_frames));
+    // todev_vf_vf("in"/"targ"), BP_GPU.cu:163-164
+    if (n_frames > 0) {
+        HIPCHK(hipMemcpyAsync(e->chunk_in, in, (size_t)n_frames * e->K0 * 4, hipMemcpyHostToDevice, e->stream));
+        if (targ)
+            HIPCHK(hipMemcpyAsync(e->chunk_targ, targ, (size_t)n_frames * e->D * 4, hipMemcpyHostToDevice, e->stream));
+    }
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->chunk_frames = n_frames;
+    return MLGGD_OK;
+}
+
+int mlggd_train_resident(mlggd_handle e, int first_frame, int n_frames, int *bunches_trained) {
+    if (!e) return fail(MLGGD_ERR_ARG, "NULL handle");
+    if (first_frame < 0 || n_frames < 0 || first_frame + n_frames > e->chunk_frames)
+        return fail(MLGGD_ERR_ARG, "frames [%d,%d) outside the resident chunk of %d frames", first_frame,
+                    first_frame + n_frames, e->chunk_frames);
+    HIPCHK(hipSetDevice(e->device));
+    int trained = 0;
+    HIPCHK(hipEventRecord(e->ev_t0, e->stream));
+    // bunch loop of BP_GPU::train, BP_GPU.cu:170-184: full bunches only
+    for (int i = 0; i + e->B <= n_frames; i += e->B) {
+        const float *in_rows = e->chunk_in + (size_t)(first_frame + i) * e->K0;
+        const float *targ_rows = e->chunk_targ + (size_t)(first_frame + i) * e->D;
+        CHK(run_step(e, in_rows, targ_rows));
+        trained++;
+    }
+    HIPCHK(hipEventRecord(e->ev_t1, e->stream));
+    e->last_steps = trained;
+    e->timing_valid = true;
+    if (bunches_trained) *bunches_trained = trained;
+    return MLGGD_OK;
+}
+
+int mlggd_sync(mlggd_handle e) {
+    if (!e) return fail(MLGGD_ERR_ARG, "NULL handle");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->comm_stream) HIPCHK(hipStreamSynchronize(e->comm_stream));
+    return MLGGD_OK;
+}
+
+int mlggd_train_chunk(mlggd_handle e, int n_frames, const float *in, const float *targ, int *bunches_trained) {
+    if (!e) return fail(MLGGD_ERR_ARG, "NULL handle");
+    if (n_frames > 0 && (!in || !targ)) return fail(MLGGD_ERR_ARG, "in/targ is NULL");
+    CHK(mlggd_load_chunk(e, n_frames, in, targ));
+    CHK(mlggd_train_resident(e, 0, n_frames, bunches_trained));
+    return mlggd_sync(e);  // BP_GPU.cu:439: train() returns after the last step completed
+}
+
+int mlggd_last_train_ms(mlggd_handle e, float *ms, int *steps) {
+    if (!e || !ms) return fail(MLGGD_ERR_ARG, "NULL argument");
+    if (!e->timing_valid) return fail(MLGGD_ERR_STATE, "no mlggd_train_resident call to time");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipEventSynchronize(e->ev_t1));
+    HIPCHK(hipEventElapsedTime(ms, e->ev_t0, e->ev_t1));
+    if (steps) *steps = e->last_steps;
+    return MLGGD_OK;
+}
+
+// Forward over a chunk whose inputs are resident: outputs into chunk_out[n][D].
+static int forward_resident(mlggd_engine *e, int n_frames) {
+    if ((size_t)n_frames > e->out_cap) {
+        if (e->chunk_out) hipFree(e->chunk_out);
+        e->chunk_out = nullptr;
+        e->out_cap = 0;
+        HIPCHK(hipMalloc((void **)&e->chunk_out, ((size_t)n_frames + 32) * e->D * sizeof(float)));
+        e->out_cap = n_frames;
+    }
+    const int b_tiles = e->Bp / 32;
+    // bunch loop of CrossValid*, BP_GPU.cu:202-216: INCLUDES the trailing partial bunch
+    for (int i = 0; i < n_frames; i += e->B) {
+        const int fb = (e->B > n_frames - i) ? (n_frames - i) : e->B;
+        CHK(run_forward(e, e->chunk_in + (size_t)i * e->K0, fb, false));
+        hipLaunchKernelGGL(k_out_rowmajor, dim3((e->Dp / 32) * b_tiles), dim3(256), 0, e->stream, e->slab, e->S_out,
+                           e->bias[e->L - 1], fb, e->D, e->Dp, e->Bp, e->chunk_out + (size_t)i * e->D, b_tiles);
+        CHK(launch_check("k_out_rowmajor"));
+    }
+    return MLGGD_OK;
+}
+
+int mlggd_forward(mlggd_handle e, int n_frames, const float *in, float *out) {
+    if (!e) return fail(MLGGD_ERR_ARG, "NULL handle");
+    if (n_frames > 0 && (!in || !out)) return fail(MLGGD_ERR_ARG, "in/out is NULL");
+    CHK(mlggd_load_chunk(e, n_frames, in, nullptr));
+    if (n_frames == 0) return MLGGD_OK;
+    CHK(forward_resident(e, n_frames));
+    HIPCHK(hipMemcpyAsync(out, e->chunk_out, (size_t)n_frames * e->D * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return MLGGD_OK;
+}
+
+// BP_GPU::Gamma, BP_GPU.cu:593-640: 10th-order polynomial on (2,3] in double powers, each
+// pair of terms rounded into a float accumulator; recurrences outside that interval.
+float mlggd_gamma(float x) {
+    static const float coef[11] = {0.0000677106, -0.0003442342, 0.0015397681, -0.0024467480, 0.0109736958,
+                                   -0.0002109075, 0.0742379071, 0.0815782188,  0.4118402518,  0.4227843370,
+                                   1.0000000000};
+    if (x > 2 && x <= 3) {
+        const double t = x - 2.0;
+        float acc = 0;
+        for (int i = 0; i < 8; i += 2) acc = acc + coef[i] * pow(t, 10.0 - i) + coef[i + 1] * pow(t, 9.0 - i);
+        acc = acc + coef[8] * pow(t, 2.0) + coef[9] * t + coef[10];
+        return acc;
+    }
+    if (x > 0 && x <= 1) return mlggd_gamma(x + 2) / (x * (x + 1));
+    if (x > 1 && x <= 2) return mlggd_gamma(x + 1) / x;
+    if (x > 3) {
+        int i = 1;
+        float prod = 1;
+        while (!((x - i) > 2 && (x - i) <= 3)) {
+            prod = (x - i) * prod;
+            i++;
+        }
+        prod = prod * (x - i);
+        return prod * mlggd_gamma(x - i);
+    }
+    return 0;
+}
+
+// Host accumulation exactly as CrossValid / CrossValiddB / CrossValid2 do it
+// (BP_GPU.cu:207-213, 240-250, 271-301): fp32 scalars, frame-major order.
+static int cv_metrics(mlggd_engine *e, int n_frames, const float *in, const float *targ, float *sqerr, float *abserr,
+                      float *loglik) {
+    if (n_frames > 0 && (!in || !targ)) return fail(MLGGD_ERR_ARG, "in/targ is NULL");
+    CHK(mlggd_load_chunk(e, n_frames, in, nullptr));
+    const int D = e->D;
+    std::vector<float> out((size_t)n_frames * D);
+    if (n_frames > 0) {
+        CHK(forward_resident(e, n_frames));
+        HIPCHK(hipMemcpyAsync(out.data(), e->chunk_out, (size_t)n_frames * D * 4, hipMemcpyDeviceToHost, e->stream));
+    }
+    std::vector<float> scalefac(D);
+    if (loglik)
+        HIPCHK(hipMemcpyAsync(scalefac.data(), e->scalefactor, (size_t)D * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const size_t total = (size_t)n_frames * D;
+    if (sqerr) {
+        float s = 0.0f;
+        for (size_t i = 0; i < total; i++) s = s + (out[i] - targ[i]) * (out[i] - targ[i]);
+        *sqerr = s;
+    }
+    if (abserr) {
+        float s = 0.0f;
+        for (size_t i = 0; i < total; i++) s = s + fabsf(out[i] - targ[i]);
+        *abserr = s / D;
+    }
+    if (loglik) {
+        const float beta = e->cfg.shapefactor;
+        float density1, density2 = 0, density3 = 0;
+        density1 = n_frames * D * logf(beta / (2 * mlggd_gamma((float)(1.0 / beta))));
+        for (int u = 0; u < D; u++) density2 += logf(scalefac[u]);
+        density2 = density2 * n_frames;
+        for (size_t i = 0; i < total; i++) {
+            const float err = targ[i] - out[i];
+            density3 += powf(fabsf(err) / scalefac[i % D], beta);
+        }
+        *loglik = density1 - density2 - density3;
+    }
+    return MLGGD_OK;
+}
+
+int mlggd_cv_sqerr(mlggd_handle e, int n, const float *in, const float *targ, float *out) {
+    if (!e || !out) return fail(MLGGD_ERR_ARG, "NULL argument");
+    return cv_metrics(e, n, in, targ, out, nullptr, nullptr);
+}
+int mlggd_cv_abserr(mlggd_handle e, int n, const float *in, const float *targ, float *out) {
+    if (!e || !out) return fail(MLGGD_ERR_ARG, "NULL argument");
+    return cv_metrics(e, n, in, targ, nullptr, out, nullptr);
+}
+int mlggd_cv_loglik(mlggd_handle e, int n, const float *in, const float *targ, float *out) {
+    if (!e || !out) return fail(MLGGD_ERR_ARG, "NULL argument");
+    return cv_metrics(e, n, in, targ, nullptr, nullptr, out);
+}
+int mlggd_cv_all(mlggd_handle e, int n, const float *in, const float *targ, float *sqerr, float *abserr,
+                 float *loglik) {
+    if (!e) return fail(MLGGD_ERR_ARG, "NULL handle");
+    return cv_metrics(e, n, in, targ, sqerr, abserr, (e->cfg.MLflag == 1) ? loglik : nullptr);
+}
+
+int mlggd_debug_tensor(mlggd_handle e, const char *name, int layer, float *dst, size_t count) {
+    if (!e || !name || !dst) return fail(MLGGD_ERR_ARG, "NULL argument");
+    HIPCHK(hipSetDevice(e->device));
+    const int L = e->L, B = e->B, Bp = e->Bp;
+    const std::string nm(name);
+    auto need = [&](size_t n) -> int {
+        return count < n ? fail(MLGGD_ERR_ARG, "dst holds %zu floats, %s needs %zu", count, name, n) : MLGGD_OK;
+    };
+    if (nm == "scalefactor") {
+        CHK(need(e->D));
+        return mlggd_get_scalefactor(e, dst);
+    }
+    if (nm == "out") {  // outT [Dp][Bp] -> [B][D]
+        CHK(need((size_t)B * e->D));
+        std::vector<float> t((size_t)e->Dp * Bp);
+        HIPCHK(hipMemcpyAsync(t.data(), e->outT, t.size() * 4, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        for (int b = 0; b < B; b++)
+            for (int d = 0; d < e->D; d++) dst[(size_t)b * e->D + d] = t[(size_t)d * Bp + b];
+        return MLGGD_OK;
+    }
+    if (layer < 1 || layer >= L) return fail(MLGGD_ERR_ARG, "layer %d not in 1..%d", layer, L - 1);
+    const int N = e->ls[layer], Np = e->lsp[layer], K = e->ls[layer - 1];
+    if (nm == "y" || nm == "dedx" || nm == "yt" || nm == "dedxt") {
+        const bool tr = (nm == "yt" || nm == "dedxt");
+        const float *src = (nm == "y") ? e->Y[layer] : (nm == "dedx") ? e->dEdX[layer]
+                           : (nm == "yt") ? e->Yt[layer] : e->dEdXt[layer];
+        if (!src) return fail(MLGGD_ERR_ARG, "%s not kept for layer %d", name, layer);
+        CHK(need((size_t)B * N));
+        std::vector<float> t((size_t)Np * Bp);
+        HIPCHK(hipMemcpyAsync(t.data(), src, t.size() * 4, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        for (int b = 0; b < B; b++)
+            for (int n = 0; n < N; n++)
+                dst[(size_t)b * N + n] = tr ? t[(size_t)n * Bp + b] : t[(size_t)b * Np + n];
+        return MLGGD_OK;
+    }
+    if (nm == "weights" || nm == "delta_w" || nm == "grad_w") {
+        const float *src = (nm == "weights") ? e->W[layer] : (nm == "delta_w") ? e->dW[layer] : e->G[layer];
+        if (!src) return fail(MLGGD_ERR_ARG, "%s not kept for layer %d", name, layer);
+        CHK(need((size_t)K * N));
+        CHK(download_padded(dst, src, Np, K, N, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        return MLGGD_OK;
+    }
+    if (nm == "bias" || nm == "delta_b") {
+        CHK(need(N));
+        HIPCHK(hipMemcpyAsync(dst, nm == "bias" ? e->bias[layer] : e->dbias[layer], (size_t)N * 4,
+                              hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        return MLGGD_OK;
+    }
+    return fail(MLGGD_ERR_ARG, "unknown tensor name '%s'", name);
+}
+
+// ---- data parallel
+int mlggd_comm_unique_id(void *id) {
+    if (!id) return fail(MLGGD_ERR_ARG, "id is NULL");
+    CHK(rccl_load());
+    RcclUniqueId uid;
+    NCCLCHK(g_rccl.GetUniqueId(&uid));
+    memcpy(id, &uid, sizeof(uid));
+    return MLGGD_OK;
+}
+
+int mlggd_comm_init(mlggd_handle e, const void *id, int world_size, int rank) {
+    if (!e || !id) return fail(MLGGD_ERR_ARG, "NULL argument");
+    if (world_size < 1 || rank < 0 || rank >= world_size)
+        return fail(MLGGD_ERR_ARG, "rank %d / world_size %d invalid", rank, world_size);
+    if (e->comm) return fail(MLGGD_ERR_STATE, "communicator already initialised");
+    if (e->cfg.dropoutflag == 1 && world_size > 1)
+        return fail(MLGGD_ERR_ARG, "dropout is not supported on the data-parallel path");
+    CHK(rccl_load());
+    HIPCHK(hipSetDevice(e->device));
+    RcclUniqueId uid;
+    memcpy(&uid, id, sizeof(uid));
+    NCCLCHK(g_rccl.CommInitRank(&e->comm, world_size, uid, rank));
+    e->world = world_size;
+    e->rank = rank;
+    HIPCHK(hipStreamCreateWithFlags(&e->comm_stream, hipStreamNonBlocking));
+    // gradient buffers (layer_ydedx / layer_sumdedx of BP_WorkSpace) only exist on this path
+    size_t gbn = 0;
+    for (int l = 1; l < e->L; l++) gbn += e->lsp[l];
+    CHK(dev_alloc(e, &e->gb_all, gbn));
+    e->gb_all_count = gbn;
+    size_t off = 0;
+    for (int l = e->L - 1; l >= 1; l--) {
+        CHK(dev_alloc(e, &e->G[l], (size_t)e->lsp[l - 1] * e->lsp[l]));
+        e->gb[l] = e->gb_all + off;
+        off += e->lsp[l];
+        HIPCHK(hipEventCreateWithFlags(&e->ev_grad[l], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&e->ev_red[l], hipEventDisableTiming));
+    }
+    HIPCHK(hipEventCreateWithFlags(&e->ev_bias, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&e->ev_bias_red, hipEventDisableTiming));
+    return MLGGD_OK;
+}
+
+// ---- per-kernel-class timing inside the timed region (bench.py roofline object)
+int mlggd_profile_select(mlggd_handle e, const char *kernel_class, int layer, int max_launches) {
+    if (!e) return fail(MLGGD_ERR_ARG, "NULL handle");
+    HIPCHK(hipSetDevice(e->device));
+    e->prof_class = -1;
+    e->prof_used = 0;
+    if (!kernel_class || !*kernel_class) return MLGGD_OK;
+    for (int c = 0; c < KC_COUNT; c++)
+        if (!strcmp(kernel_class, kKernelClassName[c])) e->prof_class = c;
+    if (e->prof_class < 0) return fail(MLGGD_ERR_ARG, "unknown kernel class '%s'", kernel_class);
+    e->prof_layer = layer;
+    if (max_launches < 1) max_launches = 1;
+    while (e->prof_ev.size() < (size_t)2 * max_launches) {
+        hipEvent_t ev;
+        HIPCHK(hipEventCreate(&ev));
+        e->prof_ev.push_back(ev);
+    }
+    return MLGGD_OK;
+}
+
+int mlggd_profile_read(mlggd_handle e, float *mean_usec, int *launches) {
+    if (!e || !mean_usec) return fail(MLGGD_ERR_ARG, "NULL argument");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    double tot = 0;
+    int n = 0;
+    for (size_t i = 0; i + 1 < e->prof_used; i += 2) {
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, e->prof_ev[i], e->prof_ev[i + 1]));
+        tot += ms;
+        n++;
+    }
+    *mean_usec = n ? (float)(tot * 1000.0 / n) : 0.0f;
+    if (launches) *launches = n;
+    e->prof_used = 0;
+    return MLGGD_OK;
+}
+
+// Static description of the launch plan (DESIGN.md "kernels"): algorithmic FLOPs and bytes of
+// one launch of the (class, layer) kernel; layer 0 = sum over layers.
+int mlggd_kernel_work(mlggd_handle e, const char *kernel_class, int layer, double *flops, double *bytes) {
+    if (!e || !kernel_class) return fail(MLGGD_ERR_ARG, "NULL argument");
+    double f = 0, by = 0;
+    const double B = e->B;
+    for (int l = 1; l < e->L; l++) {
+        if (layer != 0 && layer != l) continue;
+        const double K = e->ls[l - 1], N = e->ls[l];
+        if (!strcmp(kernel_class, "fwd")) {
+            f += 2.0 * B * K * N;
+            by += 4.0 * (K * N + B * K + 2 * B * N);
+        } else if (!strcmp(kernel_class, "dx")) {
+            if (l == 1) continue;
+            f += 2.0 * B * K * N;
+            by += 4.0 * (K * N + B * N + 3 * B * K);
+        } else if (!strcmp(kernel_class, "dw")) {
+            f += 2.0 * B * K * N;
+            by += 4.0 * (4 * K * N + B * K + B * N);  // W,delta read + written
+        }
+    }
+    if (flops) *flops = f;
+    if (bytes) *bytes = by;
+    return MLGGD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,126 @@
+"""GPU parity tests: the HIP path (through the C-ABI, libmlggd.so) against the CPU oracle on
+the same seeded inputs.  Tolerances (fp32, different but fixed summation orders; the
+reference's own cuBLAS order is unspecified):
+  activations / gradients  rtol 2e-4 of the tensor's max magnitude
+  weights after k steps    rtol 2e-5 of max |W| (updates are ~1e-3 of |W|)
+  CV metrics               1e-4 relative (the north_star tolerance)
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CASES = [(0, 2.0), (0, 1.0), (1, 2.0), (1, 1.2), (1, 0.9)]
+
+
+def relmax(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def make_pair(pkg, pyoracle, synth, ls, B, ml, beta, seed=3, lr=0.1, mom=0.9, wc=1e-5):
+    ws, bs = synth.make_weights(ls, seed=seed)
+    # non-zero biases so the bias path is exercised
+    rng = np.random.default_rng(seed + 100)
+    bs = [rng.uniform(-0.1, 0.1, b.shape).astype(np.float32) for b in bs]
+    eng = pkg.BPGpu(1234, 0, ls, B, lr, mom, wc, ws, bs, beta, ml)
+    ora = pyoracle.OracleNet(ls, B, lr, mom, wc, beta, ml, ws, bs)
+    return eng, ora
+
+
+@pytest.mark.parametrize("ml,beta", CASES)
+def test_tiny_net_three_steps(pkg, pyoracle, synth, ml, beta):
+    ls, B = [15, 8, 8, 8, 5], 8
+    eng, ora = make_pair(pkg, pyoracle, synth, ls, B, ml, beta)
+    inp, targ = synth.make_frames(3 * B + 3, 5, 3, seed=4)  # 3 full bunches + ragged tail (ignored)
+    assert eng.train(inp, targ) == 3
+    assert ora.train(inp, targ) == 3
+    we, be = eng.returnWeights()
+    wo, bo = ora.get_weights()
+    for l in range(len(we)):
+        assert relmax(we[l], wo[l]) < 2e-5, l
+        assert relmax(be[l], bo[l]) < 2e-5, l
+        assert relmax(eng.debug_tensor("delta_w", l + 1), ora.tensor("delta_w", l + 1)) < 2e-4
+    assert relmax(eng.debug_tensor("out"), ora.tensor("out", rows=B)) < 2e-4
+    assert relmax(eng.debug_tensor("dedx", 4), ora.tensor("dedx", 4, rows=B)) < 2e-4
+    if ml == 1:
+        assert relmax(eng.scalefactor(), ora.tensor("scalefactor")) < 1e-5
+    eng.close()
+
+
+@pytest.mark.parametrize("ml,beta", [(0, 2.0), (1, 1.2)])
+def test_intermediates_one_step_odd_shapes(pkg, pyoracle, synth, ml, beta):
+    # sizes that are not multiples of 32 anywhere, bunch not a multiple of 32
+    ls, B = [77, 45, 70, 33], 50
+    eng, ora = make_pair(pkg, pyoracle, synth, ls, B, ml, beta)
+    inp, targ = synth.make_frames(B, 11, 7, seed=9)
+    targ = np.ascontiguousarray(np.tile(targ, (1, 3))[:, :33])
+    eng.train(inp, targ)
+    ora.train(inp, targ)
+    for l in (1, 2):
+        assert relmax(eng.debug_tensor("y", l), ora.tensor("y", l, rows=B)) < 2e-4
+        assert relmax(eng.debug_tensor("yt", l), ora.tensor("y", l, rows=B)) < 2e-4
+    for l in (1, 2, 3):
+        assert relmax(eng.debug_tensor("dedx", l), ora.tensor("dedx", l, rows=B)) < 2e-4, l
+        assert relmax(eng.debug_tensor("dedxt", l), ora.tensor("dedx", l, rows=B)) < 2e-4, l
+        assert relmax(eng.debug_tensor("delta_w", l), ora.tensor("delta_w", l)) < 2e-4, l
+        assert relmax(eng.debug_tensor("delta_b", l), ora.tensor("delta_b", l)) < 2e-4, l
+    eng.close()
+
+
+@pytest.mark.parametrize("ml,beta", [(0, 2.0), (1, 1.2)])
+def test_baseline_net_two_steps(pkg, pyoracle, synth, ml, beta):
+    """BASELINE.json configs 2/3: 2827-2048x3-257, 128-frame minibatch."""
+    ls, B = synth.baseline_layersizes(), 128
+    eng, ora = make_pair(pkg, pyoracle, synth, ls, B, ml, beta, seed=27870775)
+    inp, targ = synth.make_frames(2 * B, 257, 11)
+    assert eng.train(inp, targ) == 2
+    assert ora.train(inp, targ) == 2
+    we, be = eng.returnWeights()
+    wo, bo = ora.get_weights()
+    for l in range(4):
+        assert relmax(we[l], wo[l]) < 2e-5, l
+        assert relmax(be[l], bo[l]) < 2e-5, l
+        assert relmax(eng.debug_tensor("delta_w", l + 1), ora.tensor("delta_w", l + 1)) < 5e-4, l
+    assert relmax(eng.debug_tensor("out"), ora.tensor("out", rows=B)) < 2e-4
+    # CV metrics incl. a ragged last bunch (300 frames = 2 bunches + 44)
+    cin, ctarg = synth.make_frames(300, 257, 11, seed=77)
+    sq, ab, ll = eng.cv_all(cin, ctarg)
+    assert abs(sq - ora.cv_sqerr(cin, ctarg)) <= 1e-4 * abs(sq)
+    assert abs(ab - ora.cv_abserr(cin, ctarg)) <= 1e-4 * abs(ab)
+    assert abs(eng.CrossValid(cin, ctarg) - sq) <= 1e-6 * abs(sq)
+    assert abs(eng.CrossValiddB(cin, ctarg) - ab) <= 1e-6 * abs(ab)
+    if ml == 1:
+        assert relmax(eng.scalefactor(), ora.tensor("scalefactor")) < 1e-5
+        assert abs(ll - ora.cv_loglik(cin, ctarg)) <= 1e-4 * abs(ll)
+        assert abs(eng.CrossValid2(cin, ctarg) - ll) <= 1e-6 * abs(ll)
+    out = eng.forward(cin)
+    assert relmax(out, ora.cv_forward(cin[:128])[:128] if False else np.vstack(
+        [ora.cv_forward(cin[i:i + 128]) for i in range(0, 300, 128)])) < 2e-4
+    eng.close()
+
+
+def test_empty_and_short_chunks(pkg, synth):
+    ls, B = [15, 8, 5], 8
+    ws, bs = synth.make_weights(ls, seed=1)
+    eng = pkg.BPGpu(1, 0, ls, B, 0.1, 0.9, 0.0, ws, bs, 2.0, 0)
+    inp, targ = synth.make_frames(5, 5, 3)
+    assert eng.train(inp[:0], targ[:0]) == 0       # empty chunk
+    assert eng.train(inp, targ) == 0               # shorter than one bunch: ignored (BP_GPU.cu:177-180)
+    w2, _ = eng.returnWeights()
+    for a, b in zip(w2, ws):
+        assert np.array_equal(a, b)
+    assert eng.forward(inp).shape == (5, 5)
+    eng.close()
+
+
+def test_errors_are_reported(pkg, synth):
+    ls = [15, 8, 5]
+    ws, bs = synth.make_weights(ls, seed=1)
+    with pytest.raises(pkg.MlggdError, match="Not In Range"):
+        pkg.BPGpu(1, 99, ls, 8, 0.1, 0.9, 0.0, ws, bs, 2.0, 0)
+    eng = pkg.BPGpu(1, 0, ls, 8, 0.1, 0.9, 0.0, ws, bs, 2.0, 0)
+    with pytest.raises(pkg.MlggdError):
+        eng.train_resident(0, 8)  # nothing resident
+    eng.close()
