@@ -132,6 +132,13 @@ int mlggd_profile_select(mlggd_handle h, const char *kernel_class, int layer, in
 int mlggd_profile_read(mlggd_handle h, float *mean_usec, int *launches);
 int mlggd_kernel_work(mlggd_handle h, const char *kernel_class, int layer, double *flops, double *bytes);
 
+/* Diagnostic (not part of the reference surface): in-kernel phase stamps of the NEXT launch of
+ * (class "fwd"|"dx"|"dw", layer): 8 int64 slots per workgroup in 100 MHz ticks
+ * (s_memrealtime); slot meaning per kernel is documented at stamp() call sites in
+ * csrc/kernels.hip.h.  The stamps go to a debug buffer only. */
+int mlggd_debug_stamp_select(mlggd_handle h, const char *kernel_class, int layer);
+int mlggd_debug_stamp_read(mlggd_handle h, long long *out /* [cap_blocks][8] */, int cap_blocks, int *blocks);
+
 #ifdef __cplusplus
 }
 #endif

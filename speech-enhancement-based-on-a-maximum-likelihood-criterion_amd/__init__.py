@@ -44,6 +44,7 @@ EXPORTS = [
     "mlggd_get_scalefactor", "mlggd_set_scalefactor", "mlggd_set_lrate", "mlggd_gamma",
     "mlggd_debug_tensor", "mlggd_comm_unique_id", "mlggd_comm_init", "mlggd_last_train_ms",
     "mlggd_profile_select", "mlggd_profile_read", "mlggd_kernel_work",
+    "mlggd_debug_stamp_select", "mlggd_debug_stamp_read",
 ]
 
 _lib = None
@@ -96,6 +97,8 @@ def load():
     L.mlggd_profile_read.argtypes = [C.c_void_p, _fp, C.POINTER(C.c_int)]
     L.mlggd_kernel_work.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_double),
                                     C.POINTER(C.c_double)]
+    L.mlggd_debug_stamp_select.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+    L.mlggd_debug_stamp_read.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.c_int, C.POINTER(C.c_int)]
     _lib = L
     return L
 
@@ -318,6 +321,17 @@ class BPGpu:
         f, b = C.c_double(0), C.c_double(0)
         _check(load().mlggd_kernel_work(self._h, kernel_class.encode(), int(layer), C.byref(f), C.byref(b)))
         return f.value, b.value
+
+
+    def stamp_select(self, kernel_class, layer):
+        _check(load().mlggd_debug_stamp_select(self._h, kernel_class.encode(), int(layer)))
+
+    def stamp_read(self, cap_blocks=8192):
+        buf = np.zeros((cap_blocks, 8), np.int64)
+        n = C.c_int(0)
+        _check(load().mlggd_debug_stamp_read(self._h, buf.ctypes.data_as(C.POINTER(C.c_longlong)), cap_blocks,
+                                             C.byref(n)))
+        return buf[:n.value]
 
 
 def shard_rows(global_frames, world_size, rank):

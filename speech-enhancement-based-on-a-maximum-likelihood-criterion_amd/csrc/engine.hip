@@ -111,12 +111,14 @@ struct mlggd_engine {
     size_t gb_all_count = 0;
     float *Yt[MLGGD_MAXLAYER] = {0}, *Y[MLGGD_MAXLAYER] = {0};
     float *dEdXt[MLGGD_MAXLAYER] = {0}, *dEdX[MLGGD_MAXLAYER] = {0};
-    float *slab = nullptr, *outT = nullptr, *eT = nullptr, *colsum = nullptr, *scalefactor = nullptr;
+    float *slab = nullptr, *outT = nullptr, *eT = nullptr, *pT = nullptr, *colsum = nullptr, *scalefactor = nullptr;
     int S_out = 1;
     float *chunk_in = nullptr, *chunk_targ = nullptr, *chunk_out = nullptr;
     size_t chunk_cap = 0, out_cap = 0;
     int chunk_frames = 0;
     unsigned step_counter = 0;
+    // launch-plan knobs (defaults chosen from measurements; env overrides for A/B runs)
+    int fwd_nw = 8, dx_nw = 8, dw_tile = 1;  // dw_tile 0 = auto
 
     // data parallel
     int world = 1, rank = 0;
@@ -133,14 +135,30 @@ struct mlggd_engine {
     size_t prof_used = 0;
     double prof_flops = 0, prof_bytes = 0;
 
+    // diagnostic in-kernel phase stamps (one launch of one (class, layer))
+    int stamp_class = -1, stamp_layer = 0, stamp_blocks = 0;
+    long long *stamp_buf = nullptr;
+    size_t stamp_cap = 0;
+
     std::vector<void *> allocs;
 };
+
+// buffer for the selected launch, nullptr otherwise; one-shot
+static long long *stamps_for(mlggd_engine *e, int cls, int layer, int blocks) {
+    if (e->stamp_class != cls || e->stamp_layer != layer || !e->stamp_buf) return nullptr;
+    if ((size_t)blocks * 8 > e->stamp_cap) return nullptr;
+    e->stamp_class = -1;
+    e->stamp_blocks = blocks;
+    return e->stamp_buf;
+}
 
 static int dev_alloc(mlggd_engine *e, float **p, size_t count) {
     // +64 floats of slack; zero-filled like the reference's devnew_vf (BP_GPU.cu:528-543)
     const size_t bytes = (count + 64) * sizeof(float);
     HIPCHK(hipMalloc((void **)p, bytes));
-    HIPCHK(hipMemset(*p, 0, bytes));
+    // on the engine's own (non-blocking) stream: a null-stream memset would not be ordered
+    // before later uploads on e->stream
+    HIPCHK(hipMemsetAsync(*p, 0, bytes, e->stream));
     e->allocs.push_back(*p);
     return MLGGD_OK;
 }
@@ -215,13 +233,19 @@ static int run_forward(mlggd_engine *e, const float *in_rows, int frames, bool t
         {
             ProfScope ps(e, KC_FWD, l);
             if (l != e->L - 1) {
-                hipLaunchKernelGGL(k_fwd<FWD_SIGMOID>, dim3(n_tiles * b_tiles), dim3(256), 0, e->stream, e->W[l],
-                                   e->Yt[l - 1], e->bias[l], e->Yt[l], e->Y[l], (float *)nullptr, Kp, Np, e->Bp,
-                                   e->ls[l], n_tiles, b_tiles, 1);
+                long long *st = stamps_for(e, KC_FWD, l, n_tiles * b_tiles);
+#define LAUNCH_FWD(NW)                                                                                              \
+    hipLaunchKernelGGL((k_fwd<FWD_SIGMOID, NW>), dim3(n_tiles * b_tiles), dim3(64 * NW), 0, e->stream, e->W[l],       \
+                       e->Yt[l - 1], e->bias[l], e->Yt[l], e->Y[l], (float *)nullptr, Kp, Np, e->Bp, e->ls[l],        \
+                       n_tiles, b_tiles, 1, st)
+                if (e->fwd_nw == 16) LAUNCH_FWD(16);
+                else if (e->fwd_nw == 8) LAUNCH_FWD(8);
+                else LAUNCH_FWD(4);
+#undef LAUNCH_FWD
             } else {
-                hipLaunchKernelGGL(k_fwd<FWD_SLAB>, dim3(n_tiles * b_tiles * e->S_out), dim3(256), 0, e->stream,
+                hipLaunchKernelGGL((k_fwd<FWD_SLAB, 4>), dim3(n_tiles * b_tiles * e->S_out), dim3(256), 0, e->stream,
                                    e->W[l], e->Yt[l - 1], e->bias[l], (float *)nullptr, (float *)nullptr, e->slab, Kp,
-                                   Np, e->Bp, e->ls[l], n_tiles, b_tiles, e->S_out);
+                                   Np, e->Bp, e->ls[l], n_tiles, b_tiles, e->S_out, (long long *)nullptr);
             }
         }
         CHK(launch_check("k_fwd"));
@@ -234,20 +258,28 @@ static int run_forward(mlggd_engine *e, const float *in_rows, int frames, bool t
     return MLGGD_OK;
 }
 
-template <int TM, int TN>
-static void launch_dw(mlggd_engine *e, int l, const float *in_rows, bool fused, float nf) {
+template <int T>
+static int launch_dw(mlggd_engine *e, int l, const float *in_rows, bool fused, float nf) {
     const int Kp = e->lsp[l - 1], Np = e->lsp[l];
-    const int k_wg = (Kp + 64 * TM - 1) / (64 * TM), n_wg = (Np + 64 * TN - 1) / (64 * TN);
+    const int k_wg = (Kp + 64 * T - 1) / (64 * T), n_wg = (Np + 64 * T - 1) / (64 * T);
     const float *A = (l == 1) ? in_rows : e->Y[l - 1];
     const int ldA = (l == 1) ? e->K0 : Kp;
+    const size_t lds = (size_t)2 * 128 * 64 * T * sizeof(float);
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[fused ? 1 : 0]) {
+        const void *fn = fused ? (const void *)k_dw<T, true> : (const void *)k_dw<T, false>;
+        HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set[fused ? 1 : 0] = true;
+    }
     if (fused)
-        hipLaunchKernelGGL((k_dw<TM, TN, true>), dim3(k_wg * n_wg), dim3(256), 0, e->stream, A, ldA, ldA, e->dEdX[l],
-                           e->W[l], e->dW[l], (float *)nullptr, e->ls[l - 1], e->ls[l], Np, e->Bp, n_wg, nf,
-                           e->cfg.momentum, e->cfg.lrate, e->cfg.weightcost);
+        hipLaunchKernelGGL((k_dw<T, true>), dim3(k_wg * n_wg), dim3(256), lds, e->stream, A, ldA, e->dEdX[l], e->W[l],
+                           e->dW[l], (float *)nullptr, e->ls[l - 1], Np, e->Bp, n_wg, nf, e->cfg.momentum,
+                           e->cfg.lrate, e->cfg.weightcost, stamps_for(e, KC_DW, l, k_wg * n_wg));
     else
-        hipLaunchKernelGGL((k_dw<TM, TN, false>), dim3(k_wg * n_wg), dim3(256), 0, e->stream, A, ldA, ldA, e->dEdX[l],
-                           e->W[l], e->dW[l], e->G[l], e->ls[l - 1], e->ls[l], Np, e->Bp, n_wg, nf, e->cfg.momentum,
-                           e->cfg.lrate, e->cfg.weightcost);
+        hipLaunchKernelGGL((k_dw<T, false>), dim3(k_wg * n_wg), dim3(256), lds, e->stream, A, ldA, e->dEdX[l], e->W[l],
+                           e->dW[l], e->G[l], e->ls[l - 1], Np, e->Bp, n_wg, nf, e->cfg.momentum, e->cfg.lrate,
+                           e->cfg.weightcost, (long long *)nullptr);
+    return launch_check("k_dw");
 }
 
 static BiasJobs make_bias_jobs(mlggd_engine *e) {
@@ -283,34 +315,44 @@ static int run_step(mlggd_engine *e, const float *in_rows, const float *targ_row
     CHK(run_forward(e, in_rows, B, true));
     {
         ProfScope ps(e, KC_LOSS, 0);
-        hipLaunchKernelGGL(k_loss_err, dim3(e->Dp / 32), dim3(256), (size_t)32 * (Bp + 1) * sizeof(float), e->stream,
-                           e->slab, e->S_out, e->bias[L - 1], targ_rows, B, e->D, e->Dp, Bp, e->cfg.shapefactor,
-                           ML == 1 ? 1 : 0, e->outT, e->eT, e->colsum);
+        const size_t lds = (size_t)(32 * (Bp + 1) + 32) * sizeof(float);
+        hipLaunchKernelGGL(k_loss_err, dim3((e->Dp / 32) * b_tiles), dim3(256), 0, e->stream, e->slab, e->S_out,
+                           e->bias[L - 1], targ_rows, B, e->D, e->Dp, Bp, e->cfg.shapefactor, ML == 1 ? 1 : 0,
+                           e->outT, e->eT, e->pT, b_tiles);
         CHK(launch_check("k_loss_err"));
-        if (dp && ML == 1)
+        const float *colsum_in = nullptr;
+        if (dp && ML == 1) {
+            hipLaunchKernelGGL(k_colsum, dim3(e->Dp / 32), dim3(256), lds, e->stream, e->pT, B, Bp, e->colsum);
+            CHK(launch_check("k_colsum"));
             NCCLCHK(g_rccl.AllReduce(e->colsum, e->colsum, (size_t)e->Dp, 7, 0, e->comm, e->stream));
-        hipLaunchKernelGGL(k_loss_grad, dim3((e->Dp / 32) * b_tiles), dim3(256), 0, e->stream, e->eT, e->colsum, B,
-                           e->D, e->Dp, Bp, e->cfg.shapefactor, ML, nf, inv_n, e->scalefactor, e->dEdXt[L - 1],
-                           e->dEdX[L - 1], b_tiles);
+            colsum_in = e->colsum;
+        }
+        hipLaunchKernelGGL(k_loss_grad, dim3((e->Dp / 32) * b_tiles), dim3(256), lds, e->stream, e->eT, e->pT,
+                           colsum_in, B, e->D, e->Dp, Bp, e->cfg.shapefactor, ML, nf, inv_n, e->scalefactor,
+                           e->dEdXt[L - 1], e->dEdX[L - 1], b_tiles);
         CHK(launch_check("k_loss_grad"));
     }
     for (int l = L - 1; l >= 1; l--) {
         const int Kp = e->lsp[l - 1], Np = e->lsp[l];
         if (l != 1) {
             ProfScope ps(e, KC_DX, l);
-            hipLaunchKernelGGL(k_dx, dim3((Kp / 32) * b_tiles), dim3(256), 0, e->stream, e->W[l], e->dEdXt[l],
-                               e->Yt[l - 1], e->dEdXt[l - 1], e->dEdX[l - 1], Kp, Np, Bp, Kp / 32, b_tiles);
+            long long *st = stamps_for(e, KC_DX, l, (Kp / 32) * b_tiles);
+            if (e->dx_nw == 8)
+                hipLaunchKernelGGL(k_dx<8>, dim3((Kp / 32) * b_tiles), dim3(512), 0, e->stream, e->W[l], e->dEdXt[l],
+                                   e->Yt[l - 1], e->dEdXt[l - 1], e->dEdX[l - 1], Kp, Np, Bp, Kp / 32, b_tiles, st);
+            else
+                hipLaunchKernelGGL(k_dx<4>, dim3((Kp / 32) * b_tiles), dim3(256), 0, e->stream, e->W[l], e->dEdXt[l],
+                                   e->Yt[l - 1], e->dEdXt[l - 1], e->dEdX[l - 1], Kp, Np, Bp, Kp / 32, b_tiles, st);
             CHK(launch_check("k_dx"));
         }
         {
             const long tiles128 = (long)((Kp + 127) / 128) * ((Np + 127) / 128);
-            const bool big = tiles128 >= 192 && Np % 128 == 0;
+            const bool big = e->dw_tile == 0 ? tiles128 >= 192 : e->dw_tile == 2;
             ProfScope ps(e, big ? KC_DW : KC_DW_SMALL, l);
             if (big)
-                launch_dw<2, 2>(e, l, in_rows, !dp, nf);
+                CHK(launch_dw<2>(e, l, in_rows, !dp, nf));
             else
-                launch_dw<1, 1>(e, l, in_rows, !dp, nf);
-            CHK(launch_check("k_dw"));
+                CHK(launch_dw<1>(e, l, in_rows, !dp, nf));
         }
         if (dp) {
             HIPCHK(hipEventRecord(e->ev_grad[l], e->stream));
@@ -323,10 +365,10 @@ static int run_step(mlggd_engine *e, const float *in_rows, const float *targ_row
         ProfScope ps(e, KC_BIAS, 0);
         BiasJobs jobs = make_bias_jobs(e);
         if (!dp) {
-            hipLaunchKernelGGL(k_bias<true>, dim3((jobs.total + 255) / 256), dim3(256), 0, e->stream, jobs, B, nf,
+            hipLaunchKernelGGL(k_bias<true>, dim3((jobs.total + 63) / 64), dim3(64), 0, e->stream, jobs, B, nf,
                                e->cfg.momentum, e->cfg.lrate);
         } else {
-            hipLaunchKernelGGL(k_bias<false>, dim3((jobs.total + 255) / 256), dim3(256), 0, e->stream, jobs, B, nf,
+            hipLaunchKernelGGL(k_bias<false>, dim3((jobs.total + 63) / 64), dim3(64), 0, e->stream, jobs, B, nf,
                                e->cfg.momentum, e->cfg.lrate);
         }
         CHK(launch_check("k_bias"));
@@ -397,6 +439,9 @@ int mlggd_create(const mlggd_config *cfg, const float *const *weights, const flo
     e->K0 = e->ls[0];
     e->D = e->ls[e->L - 1];
     e->Dp = e->lsp[e->L - 1];
+    if (const char *v = getenv("MLGGD_FWD_NW")) e->fwd_nw = atoi(v);
+    if (const char *v = getenv("MLGGD_DX_NW")) e->dx_nw = atoi(v);
+    if (const char *v = getenv("MLGGD_DW_TILE")) e->dw_tile = atoi(v);
     *out = e;  // so the caller can destroy on failure
 
     HIPCHK(hipSetDevice(e->device));
@@ -433,6 +478,7 @@ int mlggd_create(const mlggd_config *cfg, const float *const *weights, const flo
     CHK(dev_alloc(e, &e->slab, (size_t)e->S_out * e->Dp * Bp));
     CHK(dev_alloc(e, &e->outT, (size_t)e->Dp * Bp));
     CHK(dev_alloc(e, &e->eT, (size_t)e->Dp * Bp));
+    CHK(dev_alloc(e, &e->pT, (size_t)e->Dp * Bp));
     CHK(dev_alloc(e, &e->colsum, e->Dp));
     CHK(dev_alloc(e, &e->scalefactor, e->Dp));
 
@@ -853,6 +899,35 @@ int mlggd_profile_read(mlggd_handle e, float *mean_usec, int *launches) {
     *mean_usec = n ? (float)(tot * 1000.0 / n) : 0.0f;
     if (launches) *launches = n;
     e->prof_used = 0;
+    return MLGGD_OK;
+}
+
+// Diagnostic: phase stamps of the NEXT launch of (class, layer); see kernels.hip.h stamp().
+int mlggd_debug_stamp_select(mlggd_handle e, const char *kernel_class, int layer) {
+    if (!e || !kernel_class) return fail(MLGGD_ERR_ARG, "NULL argument");
+    HIPCHK(hipSetDevice(e->device));
+    if (!e->stamp_buf) {
+        e->stamp_cap = 8 * 8192;
+        HIPCHK(hipMalloc((void **)&e->stamp_buf, e->stamp_cap * sizeof(long long)));
+        e->allocs.push_back(e->stamp_buf);
+    }
+    HIPCHK(hipMemsetAsync(e->stamp_buf, 0, e->stamp_cap * sizeof(long long), e->stream));
+    e->stamp_class = -1;
+    for (int c = 0; c < KC_COUNT; c++)
+        if (!strcmp(kernel_class, kKernelClassName[c])) e->stamp_class = c;
+    if (e->stamp_class < 0) return fail(MLGGD_ERR_ARG, "unknown kernel class '%s'", kernel_class);
+    e->stamp_layer = layer;
+    e->stamp_blocks = 0;
+    return MLGGD_OK;
+}
+
+int mlggd_debug_stamp_read(mlggd_handle e, long long *out, int cap_blocks, int *blocks) {
+    if (!e || !out || !blocks) return fail(MLGGD_ERR_ARG, "NULL argument");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const int n = e->stamp_blocks < cap_blocks ? e->stamp_blocks : cap_blocks;
+    if (n > 0) HIPCHK(hipMemcpy(out, e->stamp_buf, (size_t)n * 8 * sizeof(long long), hipMemcpyDeviceToHost));
+    *blocks = n;
     return MLGGD_OK;
 }
 

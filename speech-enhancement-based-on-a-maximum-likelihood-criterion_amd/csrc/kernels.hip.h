@@ -58,27 +58,45 @@ __device__ __forceinline__ float bload(rsrc_t r, int voff, int soff) {
 __device__ __forceinline__ float4 bload4(rsrc_t r, int voff, int soff) {
     return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
+// Diagnostic phase stamps (100 MHz wall clock).  `stamps` is nullptr in every normal launch;
+// mlggd_debug_stamp_select() passes a buffer for ONE launch and the values go nowhere else.
+__device__ __forceinline__ void stamp(long long *stamps, int slot) {
+    if (stamps != nullptr && threadIdx.x == 0) {
+        stamps[(size_t)blockIdx.x * 8 + slot] = (long long)__builtin_amdgcn_s_memrealtime();
+    }
+}
 // wave index as a provably wave-uniform value (scalar branches, exact s_waitcnt counts)
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
 // ---------------------------------------------------------------------------------------
 // Forward GEMM + bias + sigmoid:   X^T[n][b] = sum_k W[k][n] * Yt_in[k][b]  (+ bias[n])
 // replaces kernMultiCopy + cublasSgemm(N,N) + kernSigmoid (BP_GPU.cu:360-364, DevFunc.cu:36-51,
-// 134-149).  One workgroup = one 32(n) x 32(b) output tile; its 4 waves (one per SIMD) split
-// the reduction K four ways and are summed through LDS in fixed order (deterministic).
+// 134-149).  One workgroup = one 32(n) x 32(b) output tile; its NW waves split the reduction
+// K and are summed through LDS in wave order (deterministic).
+//
+// Operand path (measured, DESIGN.md "why 16-byte loads"): a 4-byte-per-lane vector load costs
+// the CU's address unit as much as a 16-byte one, and two of them per MFMA cap this kernel at
+// ~60 % of the MFMA rate.  So each wave stages its OWN 32-row chunk of both operands with
+// 16-byte buffer loads (8 lanes per 128-byte row segment, 0.5 load instructions per MFMA)
+// into a wave-private LDS tile and reads the MFMA fragments back with ds_read_b32 (lanes
+// 0-31 = 32 consecutive floats, conflict-free).  LDS operations of one wave execute in
+// order, so no barrier is needed between a wave's ds_write and its own ds_read.
 // MODE FWD_SIGMOID: fused epilogue writes y=1/(1+expf(-x)) (0 for pad units) to Yt_out and Y_out.
 // MODE FWD_SLAB   : inter-workgroup K split S (small output layers); writes raw partial sums
 //                   slab[s][n][b]; the consumer adds the bias and the S slabs in order.
 // ---------------------------------------------------------------------------------------
 enum { FWD_SIGMOID = 0, FWD_SLAB = 1 };
 
-template <int MODE>
-__global__ __launch_bounds__(256) void k_fwd(const float *__restrict__ W, const float *__restrict__ Yt_in,
-                                             const float *__restrict__ bias, float *__restrict__ Yt_out,
-                                             float *__restrict__ Y_out, float *__restrict__ slab, int Kp, int Np,
-                                             int Bp, int N, int n_tiles, int b_tiles, int S) {
-    __shared__ float red[4][1024];
+template <int MODE, int NW>
+__global__ __launch_bounds__(64 * NW) void k_fwd(const float *__restrict__ W, const float *__restrict__ Yt_in,
+                                                 const float *__restrict__ bias, float *__restrict__ Yt_out,
+                                                 float *__restrict__ Y_out, float *__restrict__ slab, int Kp, int Np,
+                                                 int Bp, int N, int n_tiles, int b_tiles, int S, long long *stamps) {
+    // per wave: [32 k rows][32] of W then [32 k rows][32] of Yt (8 KB); the cross-wave
+    // reduction buffer red[NW][1024] aliases the same storage after the main loop
+    __shared__ __attribute__((aligned(16))) float smem[NW * 2048];
     __shared__ float tileT[32][33];
+    stamp(stamps, 0);
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
     const int i = lane & 31, h = lane >> 5;
     int id = blockIdx.x, s = 0;
@@ -90,100 +108,121 @@ __global__ __launch_bounds__(256) void k_fwd(const float *__restrict__ W, const 
     tile_of_block(id, n_tiles, b_tiles, nt, bt);
     const int n0 = nt * 32, b0 = bt * 32;
 
-    // k-pairs of this wave: slot = s*4+wave of S*4 slots over Kp/2 pairs
+    // k-pairs of this wave: slot = s*NW+wave of S*NW slots over Kp/2 pairs
     const int P = Kp >> 1;
-    const int slot = s * 4 + wave, nslots = S * 4;
+    const int slot = s * NW + wave, nslots = S * NW;
     const int p0 = (int)((long)P * slot / nslots), p1 = (int)((long)P * (slot + 1) / nslots);
+    const int npairs = p1 - p0;
+    const int nch = (npairs + 15) >> 4;  // chunks of 16 pairs = 32 k rows
 
     const rsrc_t rW = make_rsrc(W, (size_t)Kp * Np * 4), rY = make_rsrc(Yt_in, (size_t)Kp * Bp * 4);
-    const int voW = (h * Np + n0 + i) * 4, voY = (h * Bp + b0 + i) * 4;
-    const int wstep = 2 * Np * 4, ystep = 2 * Bp * 4;  // bytes per k-pair
+    const int r8 = lane >> 3, c4 = lane & 7;
+    const int voW = (r8 * Np + n0 + 4 * c4) * 4, voY = (r8 * Bp + b0 + 4 * c4) * 4;
+    float *stg = smem + wave * 2048;
+    float *wdst = stg + r8 * 32 + 4 * c4;
+    const float *ard = stg + h * 32 + i, *brd = stg + 1024 + h * 32 + i;
 
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[r] = 0.0f;
 
-    // 3-deep register ring of U k-pairs: 2*U*3 = 48 loads in flight (vmcnt is 6 bits),
-    // i.e. ~2 chunks = 16 MFMAs = 1024 cycles of lookahead per wave.
-    constexpr int U = 8;
-    const int nfull = (p1 - p0) / U;
-    FragU<U> f0, f1, f2;
-#define FWD_LOAD(F, C)                                              \
-    {                                                               \
-        const int pb = p0 + (C)*U;                                  \
-        _Pragma("unroll") for (int u = 0; u < U; u++) {             \
-            F.a[u] = bload(rW, voW, (pb + u) * wstep);              \
-            F.b[u] = bload(rY, voY, (pb + u) * ystep);              \
-        }                                                           \
+    float4 wa[4], ya[4], wb[4], yb[4];
+    // rows past Kp are range-checked zeros; rows past this wave's range are only ever
+    // multiplied under the npairs guard of the drain
+#define FWD_LOAD(WR, YR, C)                                                        \
+    {                                                                              \
+        const int row0 = 2 * (p0 + 16 * (C));                                      \
+        _Pragma("unroll") for (int q = 0; q < 4; q++) {                            \
+            WR[q] = bload4(rW, voW, (row0 + 8 * q) * Np * 4);                      \
+            YR[q] = bload4(rY, voY, (row0 + 8 * q) * Bp * 4);                      \
+        }                                                                          \
     }
-#define FWD_COMPUTE(F) \
-    { _Pragma("unroll") for (int u = 0; u < U; u++) acc = mfma32(F.a[u], F.b[u], acc); }
-
-    if (nfull > 0) FWD_LOAD(f0, 0);
-    if (nfull > 1) FWD_LOAD(f1, 1);
-    int c = 0;
-    // steady state: every load below is unconditional, so the compiler's s_waitcnt vmcnt(N)
-    // before each MFMA leaves the two younger chunks in flight
-    for (; c + 5 <= nfull; c += 3) {
-        FWD_LOAD(f2, c + 2);
-        FWD_COMPUTE(f0);
-        FWD_LOAD(f0, c + 3);
-        FWD_COMPUTE(f1);
-        FWD_LOAD(f1, c + 4);
-        FWD_COMPUTE(f2);
+#define FWD_WRITE(WR, YR)                                                          \
+    {                                                                              \
+        _Pragma("unroll") for (int q = 0; q < 4; q++) {                            \
+            *reinterpret_cast<float4 *>(wdst + q * 256) = WR[q];                   \
+            *reinterpret_cast<float4 *>(wdst + 1024 + q * 256) = YR[q];            \
+        }                                                                          \
+        __builtin_amdgcn_wave_barrier();                                           \
     }
-    // drain: at most 4 chunks left; f0 = chunk c, f1 = chunk c+1
-    if (c < nfull) {
-        if (c + 2 < nfull) FWD_LOAD(f2, c + 2);
-        FWD_COMPUTE(f0);
+#define FWD_COMPUTE(CNT)                                                           \
+    {                                                                              \
+        _Pragma("unroll") for (int u = 0; u < 16; u++) {                           \
+            if (u < (CNT)) acc = mfma32(ard[u * 64], brd[u * 64], acc);            \
+        }                                                                          \
+        __builtin_amdgcn_wave_barrier();                                           \
     }
-    if (c + 1 < nfull) {
-        if (c + 3 < nfull) FWD_LOAD(f0, c + 3);
-        FWD_COMPUTE(f1);
-    }
-    if (c + 2 < nfull) FWD_COMPUTE(f2);
-    if (c + 3 < nfull) FWD_COMPUTE(f0);
-    // tail pairs (< U)
-    for (int p = p0 + nfull * U; p < p1; p++) {
-        const float a = bload(rW, voW, p * wstep), b = bload(rY, voY, p * ystep);
-        acc = mfma32(a, b, acc);
+    if (nch > 0) {
+        FWD_LOAD(wa, ya, 0);
+        FWD_LOAD(wb, yb, 1);
+        int c = 0;
+        for (; c + 2 < nch; c += 2) {  // steady state: chunks c, c+1 are full; loads unconditional
+            FWD_WRITE(wa, ya);
+            FWD_LOAD(wa, ya, c + 2);
+            FWD_COMPUTE(16);
+            FWD_WRITE(wb, yb);
+            FWD_LOAD(wb, yb, c + 3);
+            FWD_COMPUTE(16);
+        }
+        FWD_WRITE(wa, ya);
+        FWD_COMPUTE(npairs - 16 * c);
+        if (c + 1 < nch) {
+            FWD_WRITE(wb, yb);
+            FWD_COMPUTE(npairs - 16 * (c + 1));
+        }
     }
 #undef FWD_LOAD
+#undef FWD_WRITE
 #undef FWD_COMPUTE
 
-    // cross-wave reduction through LDS (fixed order w = 0,1,2,3)
+    stamp(stamps, 1);
+    // cross-wave reduction through LDS (aliases the staging tiles: wait for every wave)
+    __syncthreads();
+    float(*red)[1024] = reinterpret_cast<float(*)[1024]>(smem);
 #pragma unroll
     for (int r = 0; r < 16; r++) red[wave][acc_row(r, lane) * 32 + i] = acc[r];
     __syncthreads();
-    float v[4];
+    stamp(stamps, 2);
+    // 1024 tile elements over 64*NW threads; partial sums added in wave order (deterministic)
+    constexpr int NT = 64 * NW, EPT = 1024 / NT > 0 ? 1024 / NT : 1;
+    float v[EPT];
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int e = tid + 256 * q;
-        v[q] = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
+    for (int q = 0; q < EPT; q++) {
+        const int e = tid + NT * q;
+        float sum = 0.0f;
+        if (e < 1024) {
+            sum = red[0][e];
+#pragma unroll
+            for (int w = 1; w < NW; w++) sum += red[w][e];
+        }
+        v[q] = sum;
     }
     if (MODE == FWD_SLAB) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int e = tid + 256 * q, row = e >> 5, col = e & 31;
-            slab[((size_t)s * Np + n0 + row) * Bp + b0 + col] = v[q];
+        for (int q = 0; q < EPT; q++) {
+            const int e = tid + NT * q, row = e >> 5, col = e & 31;
+            if (e < 1024) slab[((size_t)s * Np + n0 + row) * Bp + b0 + col] = v[q];
         }
     } else {
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int e = tid + 256 * q, row = e >> 5, col = e & 31;
-            const int n = n0 + row;
-            const float x = v[q] + bias[n];
-            const float y = (n < N) ? 1.0f / (1.0f + expf(-x)) : 0.0f;  // kernSigmoid, DevFunc.cu:48
-            Yt_out[(size_t)n * Bp + b0 + col] = y;
-            tileT[col][row] = y;
+        for (int q = 0; q < EPT; q++) {
+            const int e = tid + NT * q, row = e >> 5, col = e & 31;
+            if (e < 1024) {
+                const int n = n0 + row;
+                const float x = v[q] + bias[n];
+                const float y = (n < N) ? 1.0f / (1.0f + expf(-x)) : 0.0f;  // kernSigmoid, DevFunc.cu:48
+                Yt_out[(size_t)n * Bp + b0 + col] = y;
+                tileT[col][row] = y;
+            }
         }
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int e = tid + 256 * q, bl = e >> 5, nl = e & 31;
-            Y_out[(size_t)(b0 + bl) * Np + n0 + nl] = tileT[bl][nl];
+        for (int q = 0; q < EPT; q++) {
+            const int e = tid + NT * q, bl = e >> 5, nl = e & 31;
+            if (e < 1024) Y_out[(size_t)(b0 + bl) * Np + n0 + nl] = tileT[bl][nl];
         }
     }
+    stamp(stamps, 3);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -191,147 +230,135 @@ __global__ __launch_bounds__(256) void k_fwd(const float *__restrict__ W, const 
 //   dEdY^T[k][b] = sum_n W[k][n] * dEdXt[n][b] ;  dEdX_prev = (1-y)*y*dEdY
 // replaces cublasSgemm(T,N) (BP_GPU.cu:430, DevFunc.h:49-63) + kernDsigmoid of the layer
 // below (BP_GPU.cu:402, DevFunc.cu:53-71).  W is read with OLD values (launched before the
-// update of the same layer).  The reduction index n is the contiguous index of W, so each
-// wave stages its own [32 k][64 n] piece of W through LDS in full 256-byte row segments and
-// reads the A fragments back transposed (row stride 66 floats: conflict-free ds_read_b64).
+// update of the same layer).  Same structure as k_fwd (one 32x32 tile per workgroup, NW waves
+// split the reduction n, wave-private LDS staging with 16-byte loads).  The reduction index n
+// is the CONTIGUOUS index of W, so the W piece [32 k][64 n] is staged row-wise (16 lanes per
+// 256-byte row segment) and the A fragments are read back transposed (row stride 66 floats:
+// conflict-free ds_read_b64 giving two consecutive n per lane).
 // ---------------------------------------------------------------------------------------
 #define DX_LDW 66
-__global__ __launch_bounds__(256) void k_dx(const float *__restrict__ W, const float *__restrict__ dEdXt,
-                                            const float *__restrict__ Yt_prev, float *__restrict__ dEdXt_prev,
-                                            float *__restrict__ dEdX_prev, int Kp, int Np, int Bp, int k_tiles,
-                                            int b_tiles) {
-    __shared__ __attribute__((aligned(16))) float wbuf[4][32 * DX_LDW];
-    __shared__ float red[4][1024];
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_dx(const float *__restrict__ W, const float *__restrict__ dEdXt,
+                                                const float *__restrict__ Yt_prev, float *__restrict__ dEdXt_prev,
+                                                float *__restrict__ dEdX_prev, int Kp, int Np, int Bp, int k_tiles,
+                                                int b_tiles, long long *stamps) {
+    // per wave: W piece [32][66] (2112 floats) + dEdXt piece [64 n][32] (2048 floats)
+    constexpr int WSZ = 32 * DX_LDW, STG = WSZ + 2048;
+    __shared__ __attribute__((aligned(16))) float smem[NW * STG];
     __shared__ float tileT[32][33];
+    stamp(stamps, 0);
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
     const int i = lane & 31, h = lane >> 5;
     int kt, bt;
     tile_of_block(blockIdx.x, k_tiles, b_tiles, kt, bt);
     const int k0 = kt * 32, b0 = bt * 32;
 
-    const int Q = Np >> 2;   // quads of 4 consecutive n
-    const int qw = Q >> 2;   // quads per wave (Np % 32 == 0 -> exact)
+    const int Q = Np >> 2;             // quads of 4 consecutive n
+    const int qw = (Q + NW - 1) / NW;  // quads per wave (the last waves may run short or empty)
     const int q0 = wave * qw;
-    const int nch = (qw + 15) >> 4;
+    const int qend = (q0 + qw < Q) ? q0 + qw : Q;
+    const int myq = qend > q0 ? qend - q0 : 0;
+    const int nch = (myq + 15) >> 4;   // chunks of 16 quads = 64 n
 
-    const int c4 = lane & 15, r0 = lane >> 4;
-    float *wb = wbuf[wave];
-
+    float *wb = smem + wave * STG, *db = wb + WSZ;
     const rsrc_t rW = make_rsrc(W, (size_t)Kp * Np * 4), rD = make_rsrc(dEdXt, (size_t)Np * Bp * 4);
-    const int voW = ((k0 + r0) * Np + 4 * c4) * 4;  // + quad0*16 (scalar) + it*4*Np*4 (imm/scalar)
-    const int voD = (2 * h * Bp + b0 + i) * 4;
+    const int wc4 = lane & 15, wr0 = lane >> 4;  // W staging: 16 lanes per row, 4 rows per instruction
+    const int voW = ((k0 + wr0) * Np + 4 * wc4) * 4;
+    const int r8 = lane >> 3, c4 = lane & 7;      // dEdXt staging: 8 lanes per row, 8 rows per instruction
+    const int voD = (r8 * Bp + b0 + 4 * c4) * 4;
+    float *wdst = wb + wr0 * DX_LDW + 4 * wc4;
+    float *ddst = db + r8 * 32 + 4 * c4;
+    const float *ard = wb + i * DX_LDW + 2 * h;
+    const float *brd = db + 2 * h * 32 + i;
 
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[r] = 0.0f;
 
-    float4 wr[8];
-    float bA[32], bB[32];
-
-    // Quads past this wave's range (tail chunk) read in-range or zero data (range check) and
-    // are never multiplied (the j < jv guards below).
-#define DX_LOAD_W(C)                                                                       \
+    float4 wa[8], da[8], wv[8], dv[8];
+    // Quads past this wave's range read valid or range-checked-zero data and are only ever
+    // multiplied under the count guard of the drain.
+#define DX_LOAD(WR, DR, C)                                                                 \
     {                                                                                      \
-        const int sq = (q0 + (C)*16) * 16;                                                 \
-        _Pragma("unroll") for (int it = 0; it < 8; it++)                                   \
-            wr[it] = bload4(rW, voW, sq + it * (16 * Np));                                 \
-    }
-#define DX_LOAD_B(BF, C)                                                                   \
-    {                                                                                      \
-        const int sb = 4 * (q0 + (C)*16) * Bp * 4;                                         \
-        _Pragma("unroll") for (int j = 0; j < 16; j++) {                                   \
-            BF[2 * j] = bload(rD, voD, sb + (4 * j) * Bp * 4);                             \
-            BF[2 * j + 1] = bload(rD, voD, sb + (4 * j + 1) * Bp * 4);                     \
+        const int quad0 = q0 + (C)*16;                                                     \
+        _Pragma("unroll") for (int it = 0; it < 8; it++) {                                 \
+            WR[it] = bload4(rW, voW, quad0 * 16 + it * (16 * Np));                         \
+            DR[it] = bload4(rD, voD, (4 * quad0 + 8 * it) * Bp * 4);                       \
         }                                                                                  \
     }
-#define DX_STORE_LDS()                                                                     \
+#define DX_WRITE(WR, DR)                                                                   \
     {                                                                                      \
         _Pragma("unroll") for (int it = 0; it < 8; it++) {                                 \
-            float *dst = wb + (r0 + 4 * it) * DX_LDW + 4 * c4;                             \
-            *reinterpret_cast<float2 *>(dst) = make_float2(wr[it].x, wr[it].y);            \
-            *reinterpret_cast<float2 *>(dst + 2) = make_float2(wr[it].z, wr[it].w);        \
+            float *dst = wdst + (4 * it) * DX_LDW;                                         \
+            *reinterpret_cast<float2 *>(dst) = make_float2(WR[it].x, WR[it].y);            \
+            *reinterpret_cast<float2 *>(dst + 2) = make_float2(WR[it].z, WR[it].w);        \
+            *reinterpret_cast<float4 *>(ddst + it * 256) = DR[it];                         \
         }                                                                                  \
+        __builtin_amdgcn_wave_barrier();                                                   \
     }
-#define DX_COMPUTE_FULL(BF)                                                                \
+#define DX_COMPUTE(CNT)                                                                    \
     {                                                                                      \
         _Pragma("unroll") for (int j = 0; j < 16; j++) {                                   \
-            const float2 av = *reinterpret_cast<const float2 *>(wb + i * DX_LDW + 4 * j + 2 * h); \
-            acc = mfma32(av.x, BF[2 * j], acc);                                            \
-            acc = mfma32(av.y, BF[2 * j + 1], acc);                                        \
-        }                                                                                  \
-    }
-#define DX_COMPUTE(BF, C)                                                                  \
-    {                                                                                      \
-        const int jv = qw - (C)*16;                                                        \
-        _Pragma("unroll") for (int j = 0; j < 16; j++) {                                   \
-            if (j < jv) {                                                                  \
-                const float2 av = *reinterpret_cast<const float2 *>(wb + i * DX_LDW + 4 * j + 2 * h); \
-                acc = mfma32(av.x, BF[2 * j], acc);                                        \
-                acc = mfma32(av.y, BF[2 * j + 1], acc);                                    \
+            if (j < (CNT)) {                                                               \
+                const float2 av = *reinterpret_cast<const float2 *>(ard + 4 * j);          \
+                acc = mfma32(av.x, brd[(4 * j) * 32], acc);                                \
+                acc = mfma32(av.y, brd[(4 * j + 1) * 32], acc);                            \
             }                                                                              \
         }                                                                                  \
+        __builtin_amdgcn_wave_barrier();                                                   \
     }
-
-    DX_LOAD_W(0);
-    DX_LOAD_B(bA, 0);
-    int c = 0;
-    // steady state: chunks c and c+1 are not the last one, hence full (16 quads); all loads
-    // unconditional (rows past this wave's range are valid memory or range-checked zeros and
-    // are only ever multiplied under the j < jv guard of the drain below)
-    for (; c + 2 < nch; c += 2) {
-        DX_STORE_LDS();
-        __syncthreads();
-        DX_LOAD_W(c + 1);
-        DX_LOAD_B(bB, c + 1);
-        DX_COMPUTE_FULL(bA);
-        __syncthreads();
-        DX_STORE_LDS();
-        __syncthreads();
-        DX_LOAD_W(c + 2);
-        DX_LOAD_B(bA, c + 2);
-        DX_COMPUTE_FULL(bB);
-        __syncthreads();
+    if (nch > 0) {
+        DX_LOAD(wa, da, 0);
+        DX_LOAD(wv, dv, 1);
+        int c = 0;
+        for (; c + 2 < nch; c += 2) {  // steady state: full chunks, unconditional loads
+            DX_WRITE(wa, da);
+            DX_LOAD(wa, da, c + 2);
+            DX_COMPUTE(16);
+            DX_WRITE(wv, dv);
+            DX_LOAD(wv, dv, c + 3);
+            DX_COMPUTE(16);
+        }
+        DX_WRITE(wa, da);
+        DX_COMPUTE(myq - 16 * c);
+        if (c + 1 < nch) {
+            DX_WRITE(wv, dv);
+            DX_COMPUTE(myq - 16 * (c + 1));
+        }
     }
-    // drain: one or two chunks left, the last may be partial
-    DX_STORE_LDS();
-    __syncthreads();
-    if (c + 1 < nch) {
-        DX_LOAD_W(c + 1);
-        DX_LOAD_B(bB, c + 1);
-    }
-    DX_COMPUTE(bA, c);
-    __syncthreads();
-    if (c + 1 < nch) {
-        DX_STORE_LDS();
-        __syncthreads();
-        DX_COMPUTE(bB, c + 1);
-        __syncthreads();
-    }
-#undef DX_COMPUTE_FULL
-#undef DX_LOAD_W
-#undef DX_LOAD_B
-#undef DX_STORE_LDS
+#undef DX_LOAD
+#undef DX_WRITE
 #undef DX_COMPUTE
 
+    stamp(stamps, 1);
+    __syncthreads();
+    float(*red)[1024] = reinterpret_cast<float(*)[1024]>(smem);
 #pragma unroll
     for (int r = 0; r < 16; r++) red[wave][acc_row(r, lane) * 32 + i] = acc[r];
     __syncthreads();
+    stamp(stamps, 2);
+    constexpr int NT = 64 * NW, EPT = 1024 / NT > 0 ? 1024 / NT : 1;
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int e = tid + 256 * q, row = e >> 5, col = e & 31;
-        const float dedy = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
-        const size_t o = (size_t)(k0 + row) * Bp + b0 + col;
-        const float y = Yt_prev[o];
-        const float g = (1.0f - y) * y * dedy;  // kernDsigmoid, DevFunc.cu:67-68
-        dEdXt_prev[o] = g;
-        tileT[col][row] = g;
+    for (int q = 0; q < EPT; q++) {
+        const int e = tid + NT * q, row = e >> 5, col = e & 31;
+        if (e < 1024) {
+            float dedy = red[0][e];
+#pragma unroll
+            for (int w = 1; w < NW; w++) dedy += red[w][e];
+            const size_t o = (size_t)(k0 + row) * Bp + b0 + col;
+            const float y = Yt_prev[o];
+            const float g = (1.0f - y) * y * dedy;  // kernDsigmoid, DevFunc.cu:67-68
+            dEdXt_prev[o] = g;
+            tileT[col][row] = g;
+        }
     }
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int e = tid + 256 * q, bl = e >> 5, kl = e & 31;
-        dEdX_prev[(size_t)(b0 + bl) * Kp + k0 + kl] = tileT[bl][kl];
+    for (int q = 0; q < EPT; q++) {
+        const int e = tid + NT * q, bl = e >> 5, kl = e & 31;
+        if (e < 1024) dEdX_prev[(size_t)(b0 + bl) * Kp + k0 + kl] = tileT[bl][kl];
     }
+    stamp(stamps, 3);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -339,103 +366,163 @@ __global__ __launch_bounds__(256) void k_dx(const float *__restrict__ W, const f
 //   G[k][n] = sum_b Y[b][k] * dEdX[b][n]
 //   delta = mom*delta - lr*(G/n_frames + wc*W) ;  W = delta + 1.0f*W
 // replaces cublasSgemm(N,T) + kernUpdatedelta + kernAccSum (BP_GPU.cu:432-436,
-// DevFunc.cu:490-507,427-443): one pass over W/delta instead of seven.  Both operands are
-// row-major activations, so fragments are direct coalesced loads (no LDS).  4 waves = 2x2,
-// each TM x TN tiles of 32x32.  FUSED=false writes G instead (data-parallel path: the
-// gradient is all-reduced before k_apply_update).
+// DevFunc.cu:490-507,427-443): one pass over W/delta instead of seven.  This kernel is
+// HBM-bound (16 bytes of W/delta traffic per 2*B flops), so it is built around the memory
+// system:
+//  * workgroup tile 64T x 64T (T=2: 128x128), 4 waves as 2x2, wave tile 32T x 32T;
+//  * both operand tiles ([<=128 frames][64T] of Y and of dEdX, row-major) are staged ONCE
+//    into LDS with coalesced 16-byte loads (<= 128 KB, one workgroup per CU);
+//  * the W and delta tiles are prefetched into registers (coalesced 16-byte loads, 4 rows x
+//    16T floats per wave-instruction) right after staging, so they stream from HBM while the
+//    MFMA loop -- which then issues no vector-memory instruction at all -- runs from LDS;
+//  * the accumulators are transposed through LDS (operand space is dead by then) into the
+//    same row-contiguous float4 layout, updated and stored with coalesced 16-byte stores.
+// Column assignment: MFMA tile t of a wave covers columns T*i + t (i = lane&31), so one
+// ds_read_b{32T} per operand feeds all T tiles.
+// FUSED=false writes G instead (data-parallel path: all-reduced before k_apply_update).
+// Rows k >= K are skipped (layer 1 reads the caller's unpadded chunk, whose columns past K
+// alias the next frame); columns n >= N need no mask because dEdX pads are exact zeros.
 // ---------------------------------------------------------------------------------------
-template <int TM, int TN, bool FUSED>
-__global__ __launch_bounds__(256) void k_dw(const float *__restrict__ Yrow, int ldA, int Aclamp,
-                                            const float *__restrict__ dEdX, float *__restrict__ Wt,
-                                            float *__restrict__ delta, float *__restrict__ G, int K, int N, int Np,
-                                            int Bp, int n_wg, float nf, float mom, float lr, float wc) {
+template <int T> struct VecT;
+template <> struct VecT<1> { typedef float type; };
+template <> struct VecT<2> { typedef float2 type; };
+__device__ __forceinline__ float vget(float v, int) { return v; }
+__device__ __forceinline__ float vget(float2 v, int t) { return t == 0 ? v.x : v.y; }
+
+template <int T, bool FUSED>
+__global__ __launch_bounds__(256) void k_dw(const float *__restrict__ Yrow, int ldA, const float *__restrict__ dEdX,
+                                            float *__restrict__ Wt, float *__restrict__ delta,
+                                            float *__restrict__ G, int K, int Np, int Bp, int n_wg, float nf,
+                                            float mom, float lr, float wc, long long *stamps) {
+    stamp(stamps, 0);
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int TW = 64 * T;      // workgroup tile width (both dims)
+    constexpr int WT = 32 * T;      // wave tile width
+    constexpr int QPR = WT / 4;     // float4 per wave-tile row
+    constexpr int RPP = 64 / QPR;   // wave-tile rows per epilogue pass
+    constexpr int NPASS = WT / RPP; // epilogue passes (4*T*T)
+    constexpr int SQ = TW / 4;      // float4 per staged row
+    constexpr int SRP = 256 / SQ;   // staged rows per pass
+    float *As = lds, *Bs = lds + 128 * TW;
+    typedef typename VecT<T>::type vec_t;
+
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
     const int i = lane & 31, h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
     const int kt = blockIdx.x / n_wg, ntile = blockIdx.x % n_wg;
-    const int k0 = kt * (64 * TM) + wm * (32 * TM), n0 = ntile * (64 * TN) + wn * (32 * TN);
+    const int k0 = kt * TW, n0 = ntile * TW;
 
     const rsrc_t rA = make_rsrc(Yrow, (size_t)Bp * ldA * 4), rB = make_rsrc(dEdX, (size_t)Bp * Np * 4);
-    int va[TM], vb[TN];
-#pragma unroll
-    for (int t = 0; t < TM; t++) {
-        int col = k0 + 32 * t + i;
-        col = col < Aclamp ? col : Aclamp - 1;
-        va[t] = (h * ldA + col) * 4;
-    }
-#pragma unroll
-    for (int t = 0; t < TN; t++) {
-        int col = n0 + 32 * t + i;
-        col = col < Np ? col : Np - 1;
-        vb[t] = (h * Np + col) * 4;
-    }
-    const int astep = 2 * ldA * 4, bstep = 2 * Np * 4;  // bytes per frame pair
 
-    f32x16 acc[TM][TN];
+    f32x16 acc[T][T];
 #pragma unroll
-    for (int tm = 0; tm < TM; tm++)
+    for (int tm = 0; tm < T; tm++)
 #pragma unroll
-        for (int tn = 0; tn < TN; tn++)
+        for (int tn = 0; tn < T; tn++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[tm][tn][r] = 0.0f;
 
-    constexpr int U = 8;
-    const int nch = (Bp >> 1) / U;  // Bp % 32 == 0 -> exact
-    float a0[TM][U], b0[TN][U], a1[TM][U], b1[TN][U];
-#define DW_LOAD(A, B, C)                                                                         \
-    {                                                                                            \
-        _Pragma("unroll") for (int u = 0; u < U; u++) {                                          \
-            _Pragma("unroll") for (int t = 0; t < TM; t++) A[t][u] = bload(rA, va[t], ((C)*U + u) * astep); \
-            _Pragma("unroll") for (int t = 0; t < TN; t++) B[t][u] = bload(rB, vb[t], ((C)*U + u) * bstep); \
-        }                                                                                        \
-    }
-#define DW_COMPUTE(A, B)                                                                         \
-    {                                                                                            \
-        _Pragma("unroll") for (int u = 0; u < U; u++)                                            \
-            _Pragma("unroll") for (int tm = 0; tm < TM; tm++)                                    \
-                _Pragma("unroll") for (int tn = 0; tn < TN; tn++)                                \
-                    acc[tm][tn] = mfma32(A[tm][u], B[tn][u], acc[tm][tn]);                       \
-    }
-    DW_LOAD(a0, b0, 0);
-    int c = 0;
-    for (; c + 2 < nch; c += 2) {  // steady state: unconditional loads
-        DW_LOAD(a1, b1, c + 1);
-        DW_COMPUTE(a0, b0);
-        DW_LOAD(a0, b0, c + 2);
-        DW_COMPUTE(a1, b1);
-    }
-    if (c + 1 < nch) {
-        DW_LOAD(a1, b1, c + 1);
-        DW_COMPUTE(a0, b0);
-        DW_COMPUTE(a1, b1);
-    } else {
-        DW_COMPUTE(a0, b0);
-    }
-#undef DW_LOAD
-#undef DW_COMPUTE
+    // epilogue geometry (also the prefetch geometry)
+    const int ec = lane % QPR, er = lane / QPR;
+    const int gk0 = k0 + WT * wm + er, gn = n0 + WT * wn + 4 * ec;
+    float4 wreg[NPASS], dreg[NPASS];
 
+    const int scol = tid % SQ, srow = tid / SQ;
+    for (int bc = 0; bc < Bp; bc += 128) {
+        const int rows = (Bp - bc < 128) ? (Bp - bc) : 128;
+        // ---- stage both operand tiles, 8 float4 per operand per batch
+        for (int r0 = 0; r0 < rows; r0 += 8 * SRP) {
+            float4 sa[8], sb[8];
 #pragma unroll
-    for (int tm = 0; tm < TM; tm++)
+            for (int q = 0; q < 8; q++) {
+                const int row = r0 + srow + q * SRP;
+                sa[q] = bload4(rA, ((bc + row) * ldA + k0 + 4 * scol) * 4, 0);
+                sb[q] = bload4(rB, ((bc + row) * Np + n0 + 4 * scol) * 4, 0);
+            }
 #pragma unroll
-        for (int tn = 0; tn < TN; tn++) {
-            const int n = n0 + 32 * tn + i;
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int k = k0 + 32 * tm + acc_row(r, lane);
-                if (k < K && n < N) {
-                    const size_t idx = (size_t)k * Np + n;
-                    const float g = acc[tm][tn][r];
-                    if (FUSED) {
-                        const float w = Wt[idx];
-                        const float d = mom * delta[idx] - lr * (g / nf + wc * w);  // kernUpdatedelta, DevFunc.cu:502
-                        delta[idx] = d;
-                        Wt[idx] = d + 1.0f * w;                                    // kernAccSum, DevFunc.cu:440
-                    } else {
-                        G[idx] = g;
-                    }
+            for (int q = 0; q < 8; q++) {
+                const int row = r0 + srow + q * SRP;
+                if (row < rows) {
+                    *reinterpret_cast<float4 *>(As + row * TW + 4 * scol) = sa[q];
+                    *reinterpret_cast<float4 *>(Bs + row * TW + 4 * scol) = sb[q];
                 }
             }
         }
+        __syncthreads();
+        if (bc == 0) stamp(stamps, 1);
+        if (FUSED && bc == 0) {
+            // W / delta prefetch: in flight during the whole MFMA loop
+#pragma unroll
+            for (int it = 0; it < NPASS; it++) {
+                const int k = gk0 + RPP * it;
+                if (k < K && gn < Np) {
+                    const size_t idx = (size_t)k * Np + gn;
+                    wreg[it] = *reinterpret_cast<const float4 *>(Wt + idx);
+                    dreg[it] = *reinterpret_cast<const float4 *>(delta + idx);
+                } else {
+                    wreg[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    dreg[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+        }
+        if (bc == 0) stamp(stamps, 2);
+        // ---- MFMA loop over frame pairs, operands from LDS only
+        const float *ap = As + h * TW + WT * wm + T * i;
+        const float *bp = Bs + h * TW + WT * wn + T * i;
+        for (int p0 = 0; p0 < rows / 2; p0 += 8) {  // rows % 32 == 0
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const vec_t a = *reinterpret_cast<const vec_t *>(ap + 2 * (p0 + u) * TW);
+                const vec_t b = *reinterpret_cast<const vec_t *>(bp + 2 * (p0 + u) * TW);
+#pragma unroll
+                for (int tm = 0; tm < T; tm++)
+#pragma unroll
+                    for (int tn = 0; tn < T; tn++) acc[tm][tn] = mfma32(vget(a, tm), vget(b, tn), acc[tm][tn]);
+            }
+        }
+        __syncthreads();
+    }
+
+    stamp(stamps, 3);
+    // ---- epilogue: accumulators -> LDS (wave-private [WT][WT] tile) -> row-contiguous float4
+    float *Tw = lds + wave * (WT * WT);
+#pragma unroll
+    for (int tm = 0; tm < T; tm++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int kl = T * acc_row(r, lane) + tm;
+            if (T == 2) {
+                *reinterpret_cast<float2 *>(Tw + kl * WT + 2 * i) = make_float2(acc[tm][0][r], acc[tm][T - 1][r]);
+            } else {
+                Tw[kl * WT + i] = acc[tm][0][r];
+            }
+        }
+    __syncthreads();
+    stamp(stamps, 4);
+#pragma unroll
+    for (int it = 0; it < NPASS; it++) {
+        const int kl = er + RPP * it;
+        const int k = gk0 + RPP * it;
+        const float4 g = *reinterpret_cast<const float4 *>(Tw + kl * WT + 4 * ec);
+        if (k < K && gn < Np) {
+            const size_t idx = (size_t)k * Np + gn;
+            if (FUSED) {
+                const float4 w = wreg[it];
+                float4 d = dreg[it];
+                // kernUpdatedelta (DevFunc.cu:502) then kernAccSum (DevFunc.cu:440)
+                d.x = mom * d.x - lr * (g.x / nf + wc * w.x);
+                d.y = mom * d.y - lr * (g.y / nf + wc * w.y);
+                d.z = mom * d.z - lr * (g.z / nf + wc * w.z);
+                d.w = mom * d.w - lr * (g.w / nf + wc * w.w);
+                *reinterpret_cast<float4 *>(delta + idx) = d;
+                *reinterpret_cast<float4 *>(Wt + idx) =
+                    make_float4(d.x + 1.0f * w.x, d.y + 1.0f * w.y, d.z + 1.0f * w.z, d.w + 1.0f * w.w);
+            } else {
+                *reinterpret_cast<float4 *>(G + idx) = g;
+            }
+        }
+    }
+    stamp(stamps, 5);
 }
 
 // Elementwise update from an (all-reduced) gradient, data-parallel path.  Pad entries have
@@ -478,7 +565,7 @@ struct BiasJobs {
 };
 
 template <bool FUSED>
-__global__ __launch_bounds__(256) void k_bias(BiasJobs jobs, int B, float nf, float mom, float lr) {
+__global__ __launch_bounds__(64) void k_bias(BiasJobs jobs, int B, float nf, float mom, float lr) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= jobs.total) return;
     int j = 0;
@@ -490,7 +577,15 @@ __global__ __launch_bounds__(256) void k_bias(BiasJobs jobs, int B, float nf, fl
     if (n >= jb.N) return;
     const float *p = jb.dEdX + n;
     float s = p[0];
-    for (int b = 1; b < B; b++) s += p[(size_t)b * jb.Np];
+    int b = 1;
+    for (; b + 16 <= B; b += 16) {  // 16 independent loads in flight, adds stay in frame order
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) v[u] = p[(size_t)(b + u) * jb.Np];
+#pragma unroll
+        for (int u = 0; u < 16; u++) s += v[u];
+    }
+    for (; b < B; b++) s += p[(size_t)b * jb.Np];
     if (FUSED) {
         const float bv = jb.bias[n];
         const float d = mom * jb.dbias[n] - lr * (s / nf + 0.0f * bv);
@@ -541,45 +636,83 @@ __global__ __launch_bounds__(256) void k_transpose_in(const float *__restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------
-// Output-layer loss, phase A: out = bias + sum_s slab[s]; e = out - targ; per-dimension
-// sum_b |e|^beta in the reference's order (kernerror, kernabsolutevalus, kernindex2,
-// kernSumcol: DevFunc.cu:399-409,186-191,219-227,167-185 <- BP_GPU.cu:413-416).
-// One workgroup per 32 output dims; writes outT, eT ([Dp][Bp], 0 in pads) and colsum[d].
-// Dynamic LDS: 32*(Bp+1) floats.
+// Output-layer loss, phase A (elementwise, one workgroup per 32(d) x 32(b) tile):
+//   out = bias + sum_s slab[s];  e = out - targ;  p = |e|^beta
+// kernerror, kernabsolutevalus, kernindex2 (DevFunc.cu:399-409,186-191,219-227 <-
+// BP_GPU.cu:413-415).  Writes outT, eT, pT, all [Dp][Bp] with zeros in the pads.  targ is the
+// caller's row-major [B][D]; it is read in 128-byte row segments and transposed through LDS.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_loss_err(const float *__restrict__ slab, int S, const float *__restrict__ bias,
                                                   const float *__restrict__ targ, int B, int D, int Dp, int Bp,
-                                                  float beta, int want_colsum, float *__restrict__ outT,
-                                                  float *__restrict__ eT, float *__restrict__ colsum) {
-    extern __shared__ __attribute__((aligned(16))) float a2[];  // [32][Bp+1]
-    const int d0 = blockIdx.x * 32;
-    const int total = 32 * Bp;
-    for (int idx = threadIdx.x; idx < total; idx += 256) {
-        const int dl = idx / Bp, b = idx - dl * Bp;
-        const int d = d0 + dl;
+                                                  float beta, int want_pow, float *__restrict__ outT,
+                                                  float *__restrict__ eT, float *__restrict__ pT, int b_tiles) {
+    __shared__ float tt[32][33];
+    const int dt = blockIdx.x / b_tiles, bt = blockIdx.x % b_tiles;
+    const int d0 = dt * 32, b0 = bt * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int b = b0 + ty + 8 * q, d = d0 + tx;
+        tt[ty + 8 * q][tx] = (b < B && d < D) ? targ[(size_t)b * D + d] : 0.0f;
+    }
+    __syncthreads();
+    const size_t slab_stride = (size_t)Dp * Bp;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int dl = ty + 8 * q, d = d0 + dl, b = b0 + tx;
         const size_t o = (size_t)d * Bp + b;
         float x = slab[o];
-        for (int s = 1; s < S; s++) x += slab[(size_t)s * Dp * Bp + o];
+#pragma unroll 4
+        for (int s = 1; s < S; s++) x += slab[(size_t)s * slab_stride + o];
         x = x + bias[d];
         float e = 0.0f, p = 0.0f;
         if (b < B && d < D) {
-            e = x - targ[(size_t)b * D + d];  // kernerror
-            if (want_colsum) p = powf(fabsf(e), beta);  // kernabsolutevalus + kernindex2
+            e = x - tt[tx][dl];                       // kernerror
+            if (want_pow) p = powf(fabsf(e), beta);   // kernabsolutevalus + kernindex2
         } else {
             x = 0.0f;
         }
         outT[o] = x;
         eT[o] = e;
-        a2[dl * (Bp + 1) + b] = p;
+        pT[o] = p;
     }
-    if (!want_colsum) return;
+}
+
+// Per-dimension sum over the minibatch of |e|^beta in the reference's order (kernSumcol,
+// DevFunc.cu:167-185 <- BP_GPU.cu:416: one thread per column, rows added sequentially).
+// Shared by k_colsum (data-parallel path: the local sum is all-reduced) and k_loss_grad.
+// rows: LDS [32][Bp+1]; must be called by all 256 threads.
+__device__ __forceinline__ void colsum_tile(const float *__restrict__ pT, int d0, int B, int Bp, float *rows,
+                                            float *sums) {
+    const int total = 32 * Bp;
+    for (int idx = threadIdx.x; idx < total; idx += 256) {
+        const int dl = idx / Bp, b = idx - dl * Bp;
+        rows[dl * (Bp + 1) + b] = pT[(size_t)(d0 + dl) * Bp + b];
+    }
     __syncthreads();
     if (threadIdx.x < 32) {
-        const float *col = a2 + threadIdx.x * (Bp + 1);
+        const float *col = rows + threadIdx.x * (Bp + 1);
         float s = col[0];  // kernSumcol: (*top) = (*fromp); then += in row order
-        for (int b = 1; b < B; b++) s += col[b];
-        colsum[d0 + threadIdx.x] = s;
+        int b = 1;
+        for (; b + 16 <= B; b += 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) v[u] = col[b + u];
+#pragma unroll
+            for (int u = 0; u < 16; u++) s += v[u];
+        }
+        for (; b < B; b++) s += col[b];
+        sums[threadIdx.x] = s;
     }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_colsum(const float *__restrict__ pT, int B, int Bp,
+                                                float *__restrict__ colsum) {
+    extern __shared__ __attribute__((aligned(16))) float dyn[];
+    float *rows = dyn, *sums = dyn + 32 * (Bp + 1);
+    colsum_tile(pT, blockIdx.x * 32, B, Bp, rows, sums);
+    if (threadIdx.x < 32) colsum[blockIdx.x * 32 + threadIdx.x] = sums[threadIdx.x];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -588,28 +721,38 @@ __global__ __launch_bounds__(256) void k_loss_err(const float *__restrict__ slab
 // MLflag == 1: alpha_d = (beta * colsum_d / n)^(1/beta) (kernDivide, kernVecMulNum,
 // kernindex2 <- BP_GPU.cu:417-420), g = sgn(e)|e|^(beta-1) * beta / alpha^beta / n
 // (kernfunc2 + kernVecMulNum, DevFunc.cu:468-489 <- BP_GPU.cu:422-423).
-// colsum is the GLOBAL minibatch sum (all-reduced in data-parallel runs), nf the global
-// minibatch size.  One workgroup per 32(d) x 32(b) tile; writes dEdXt and dEdX.
+// colsum_in == nullptr: the workgroup sums its 32 columns of pT itself (single GPU);
+// otherwise colsum_in is the GLOBAL minibatch sum (all-reduced).  nf = global minibatch size.
+// One workgroup per 32(d) x 32(b) tile; writes dEdXt and dEdX.  Dynamic LDS: 32*(Bp+1)+32 floats.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_loss_grad(const float *__restrict__ eT, const float *__restrict__ colsum,
-                                                   int B, int D, int Dp, int Bp, float beta, int MLflag, float nf,
-                                                   float inv_n, float *__restrict__ scalefactor,
-                                                   float *__restrict__ dEdXt, float *__restrict__ dEdX, int b_tiles) {
+__global__ __launch_bounds__(256) void k_loss_grad(const float *__restrict__ eT, const float *__restrict__ pT,
+                                                   const float *__restrict__ colsum_in, int B, int D, int Dp, int Bp,
+                                                   float beta, int MLflag, float nf, float inv_n,
+                                                   float *__restrict__ scalefactor, float *__restrict__ dEdXt,
+                                                   float *__restrict__ dEdX, int b_tiles) {
+    extern __shared__ __attribute__((aligned(16))) float dyn[];
     __shared__ float tileT[32][33];
     __shared__ float denom[32];
     const int dt = blockIdx.x / b_tiles, bt = blockIdx.x % b_tiles;
     const int d0 = dt * 32, b0 = bt * 32;
     const int tid = threadIdx.x;
     if (MLflag == 1) {
+        float *rows = dyn, *sums = dyn + 32 * (Bp + 1);
+        if (colsum_in == nullptr) {
+            colsum_tile(pT, d0, B, Bp, rows, sums);
+        } else {
+            if (tid < 32) sums[tid] = colsum_in[d0 + tid];
+            __syncthreads();
+        }
         if (tid < 32) {
             const int d = d0 + tid;
             float q = 1.0f;
             if (d < D) {
-                const float v1 = colsum[d] / nf;          // kernDivide
-                const float v2 = v1 * beta;               // kernVecMulNum
+                const float v1 = sums[tid] / nf;            // kernDivide
+                const float v2 = v1 * beta;                 // kernVecMulNum
                 const float alpha = powf(v2, 1.0f / beta);  // kernindex2 with ppp = 1.0f/shapefactor
                 if (bt == 0) scalefactor[d] = alpha;
-                q = powf(alpha, beta);                    // pow(vec[j], alpha) in kernfunc2
+                q = powf(alpha, beta);                      // pow(vec[j], alpha) in kernfunc2
             }
             denom[tid] = q;
         }

@@ -1,0 +1,208 @@
+// bptrain_main.cc -- the trainer executable (drop-in for the reference's BPtrain_Sigmoid,
+// Train_code_ML_GGD/BPtrain.cc:55-146): same key=value command line as emitted by
+// finetune.pl:50-76, same log lines, same .wts output; one epoch per process.
+//
+// Flow (BPtrain.cc:74-145): Initial -> BP_GPU -> get_pfile_info -> plan training chunks ->
+// shuffle the chunk order (one lrand48 stream: chunk order first, then one shuffle per chunk
+// read, in read order) -> prefetch thread reads chunk i+1 while the GPU trains on chunk i ->
+// write weights -> cross-validate -> three log lines.
+//
+// Data parallel (new): when WORLD_SIZE > 1 (torchrun-style env: RANK,
+// LOCAL_RANK, WORLD_SIZE; MLGGD_ID_FILE names a file on a shared filesystem used to hand the
+// RCCL unique id from rank 0 to the others) every rank reads the same chunks with the same
+// seed and trains rows [rank*bunchsize,(rank+1)*bunchsize) of each global minibatch of
+// WORLD_SIZE*bunchsize samples; rank 0 alone writes the log, the weights and runs CV.
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+#include <unistd.h>
+
+#include "bp_gpu.h"
+#include "trainer_io.h"
+
+using mlggd_host::Interface;
+using mlggd_host::IoError;
+using mlggd_host::WorkPara;
+
+namespace {
+
+// Two-slot hand-off between the fetch thread and the trainer (waitSignal/setSignal,
+// Interface.cc:14-53, with a predicate loop instead of a single `if`).
+struct Slot {
+    std::mutex m;
+    std::condition_variable cv;
+    bool full = false;
+    void wait(bool want) {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return full == want; });
+    }
+    void set(bool v) {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            full = v;
+        }
+        cv.notify_all();
+    }
+};
+
+void swap_buffers(WorkPara *p) {  // BPtrain.cc:25-32
+    std::swap(p->indata[0], p->indata[1]);
+    std::swap(p->targ[0], p->targ[1]);
+}
+
+// threadFetch, BPtrain.cc:15-54
+void fetch_loop(Interface *io, Slot *slot, std::string *error) {
+    try {
+        for (unsigned i = 0; i < io->total_chunks; i++) {
+            const int n = io->Readchunk(io->chunk_index[i]);  // into indata[0]/targ[0]
+            if (i > 0) slot->wait(false);                      // trainer done with indata[1]
+            io->cur_chunk_samples = n;
+            swap_buffers(io->para);
+            slot->set(true);
+        }
+    } catch (const std::exception &e) {
+        *error = e.what();
+        io->cur_chunk_samples = -1;
+        slot->set(true);
+    }
+}
+
+int env_int(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
+// rank 0 writes the RCCL id to MLGGD_ID_FILE (atomically, via rename); the others poll for it
+void exchange_id(int rank, unsigned char id[MLGGD_UNIQUE_ID_BYTES]) {
+    const char *path = getenv("MLGGD_ID_FILE");
+    if (!path || !*path) throw IoError("WORLD_SIZE > 1 needs MLGGD_ID_FILE (path visible to every rank)");
+    if (rank == 0) {
+        if (mlggd_comm_unique_id(id) != MLGGD_OK) throw IoError(mlggd_last_error());
+        const std::string tmp = std::string(path) + ".tmp";
+        FILE *fp = fopen(tmp.c_str(), "wb");
+        if (!fp || fwrite(id, 1, MLGGD_UNIQUE_ID_BYTES, fp) != MLGGD_UNIQUE_ID_BYTES) throw IoError("cannot write MLGGD_ID_FILE");
+        fclose(fp);
+        if (rename(tmp.c_str(), path) != 0) throw IoError("cannot publish MLGGD_ID_FILE");
+    } else {
+        for (int tries = 0; tries < 6000; tries++) {
+            FILE *fp = fopen(path, "rb");
+            if (fp) {
+                const size_t n = fread(id, 1, MLGGD_UNIQUE_ID_BYTES, fp);
+                fclose(fp);
+                if (n == MLGGD_UNIQUE_ID_BYTES) return;
+            }
+            usleep(10000);
+        }
+        throw IoError("timed out waiting for MLGGD_ID_FILE");
+    }
+}
+
+}  // namespace
+
+int main(int argc, char *argv[]) {
+    const double t_start = (double)time(NULL);
+    printf("--------activation functin is sigmoid--------\n");  // BPtrain.cc:71
+    const int world = env_int("WORLD_SIZE", 1), rank = env_int("RANK", 0);
+    const int local_rank = env_int("LOCAL_RANK", rank);
+    Interface *io = new Interface;
+    try {
+        io->Initial(argc, argv, /*open_output=*/rank == 0);
+        WorkPara *p = io->para;
+        const int device = world > 1 ? local_rank : p->gpu_used;
+        BP_GPU *net = new BP_GPU(p->init_randem_seed, device, io->numlayers, p->layersizes, p->bunchsize, p->lrate,
+                                 p->momentum, p->weightcost, p->weights, p->bias, p->shapefactor, p->MLflag,
+                                 p->dropoutflag, p->visible_omit, p->hid_omit);
+        if (world > 1) {
+            unsigned char id[MLGGD_UNIQUE_ID_BYTES];
+            exchange_id(rank, id);
+            net->joinComm(id, world, rank);
+        }
+        io->get_pfile_info();
+
+        // ---- train (BPtrain.cc:81-102)
+        io->get_chunk_info(p->train_sent_range);
+        io->chunk_index.resize(io->total_chunks);
+        for (unsigned i = 0; i < io->total_chunks; i++) io->chunk_index[i] = (int)i;
+        io->GetRandIndex(io->chunk_index.data(), (int)io->total_chunks);
+
+        Slot slot;
+        std::string fetch_error;
+        std::thread fetch(fetch_loop, io, &slot, &fetch_error);
+        const int K0 = p->layersizes[0], D = p->layersizes[io->numlayers - 1], B = p->bunchsize;
+        std::vector<float> loc_in, loc_targ;
+        for (unsigned i = 0; i < io->total_chunks; i++) {
+            slot.wait(true);
+            if (io->cur_chunk_samples < 0) break;
+            io->logf("Starting chunk %d of %d containing %d samples.\n", i + 1, io->total_chunks, io->cur_chunk_samples);
+            if (io->fp_log) fflush(io->fp_log);
+            if (world == 1) {
+                net->train(io->cur_chunk_samples, p->indata[1], p->targ[1]);
+            } else {
+                // this rank's rows of every complete global minibatch, compacted
+                const int gb = B * world, nglob = io->cur_chunk_samples / gb;
+                loc_in.resize((size_t)nglob * B * K0);
+                loc_targ.resize((size_t)nglob * B * D);
+                for (int g = 0; g < nglob; g++) {
+                    const size_t src = (size_t)g * gb + (size_t)rank * B;
+                    memcpy(&loc_in[(size_t)g * B * K0], p->indata[1] + src * K0, (size_t)B * K0 * sizeof(float));
+                    memcpy(&loc_targ[(size_t)g * B * D], p->targ[1] + src * D, (size_t)B * D * sizeof(float));
+                }
+                net->train(nglob * B, loc_in.data(), loc_targ.data());
+            }
+            slot.set(false);
+        }
+        fetch.join();
+        if (!fetch_error.empty()) throw IoError(fetch_error);
+
+        io->logf("Total cost time: %.1f s.\n", (double)time(NULL) - t_start);  // BPtrain.cc:104-105
+
+        if (rank == 0) {
+            printf("begin to write weights\n");
+            net->returnWeights(p->weights, p->bias);
+            io->Writeweights();
+            printf("finish to write weights\n\n");
+
+            // ---- CV (BPtrain.cc:112-140)
+            printf("begin to CV\n");
+            io->logf("Starting CV.\n");
+            io->get_chunk_info_cv(p->cv_sent_range);
+            float squared_err = 0.0f, dB_squared_err = 0.0f, likelihood = 0.0f;
+            for (unsigned i = 0; i < io->cv_total_chunks; i++) {
+                const int n = io->Readchunk_cv((int)i);
+                printf("cur_chunk_samples=%d\n", n);
+                float sq = 0, ab = 0, ll = 0;
+                net->CrossValidAll(n, p->indata[0], p->targ[0], &sq, &ab, &ll);
+                squared_err += sq;
+                dB_squared_err += ab;
+                if (p->MLflag == 1) likelihood += ll;
+            }
+            const float cvacc = ((float)squared_err / io->cv_total_samples);
+            io->logf("CV over. squared error: %f\n", cvacc);
+            const float cvacc1 = ((float)dB_squared_err / io->cv_total_samples);
+            io->logf("CV over. square root squared error: %f\n", cvacc1);
+            if (p->MLflag == 1) {
+                const float cvacc2 = ((float)likelihood / io->cv_total_samples);
+                io->logf("CV2 over. CV log likelihood: %f\n", cvacc2);
+            }
+            if (io->fp_log) fflush(io->fp_log);
+        }
+        printf("all finish!\n");
+        delete net;
+        delete io;
+    } catch (const std::exception &e) {
+        // the reference writes the message to the log and exit(0)s (e.g. Interface.cc:320,325,451);
+        // same message, non-zero status
+        io->logf("%s\n", e.what());
+        if (io->fp_log) fflush(io->fp_log);
+        fprintf(stderr, "%s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

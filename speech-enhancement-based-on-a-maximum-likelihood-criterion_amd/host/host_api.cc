@@ -1,0 +1,102 @@
+// host_api.cc -- C entry points over trainer_io for the CPU test-suite (ctypes): lets
+// tests/ drive the real host code (CLI parse, pfile reader, chunk planner, chunk reader,
+// .wts writer) without a GPU and compare it with an independent NumPy restatement.
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "trainer_io.h"
+
+using namespace mlggd_host;
+
+static thread_local std::string g_err;
+
+extern "C" {
+
+const char *mlggd_host_last_error() { return g_err.c_str(); }
+
+void *mlggd_host_open(int argc, char **argv) {
+    Interface *io = new Interface;
+    try {
+        io->Initial(argc, argv, false);
+        io->get_pfile_info();
+        return io;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        delete io;
+        return nullptr;
+    }
+}
+
+void mlggd_host_close(void *h) { delete (Interface *)h; }
+
+int mlggd_host_info(void *h, unsigned *sents, unsigned *frames, int *table, int cap) {
+    Interface *io = (Interface *)h;
+    *sents = io->total_sents;
+    *frames = io->total_frames;
+    for (unsigned i = 0; i < io->total_sents && (int)i < cap; i++) table[i] = io->framesBeforeSent[i];
+    return io->numlayers;
+}
+
+int mlggd_host_norm(void *h, float *mean, float *inv_std, int cap) {
+    Interface *io = (Interface *)h;
+    const int n = (int)io->mean().size();
+    for (int i = 0; i < n && i < cap; i++) {
+        mean[i] = io->mean()[i];
+        inv_std[i] = io->inv_std()[i];
+    }
+    return n;
+}
+
+// plans chunks for `range`; cv != 0 selects the CV planner.  Returns total_chunks (or -1).
+int mlggd_host_plan(void *h, const char *range, int cv, int *starts, int cap, unsigned *total_samples) {
+    Interface *io = (Interface *)h;
+    try {
+        if (cv) io->get_chunk_info_cv(range); else io->get_chunk_info(range);
+        const ChunkPlan &pl = cv ? io->cv_plan : io->train_plan;
+        for (unsigned i = 0; i < pl.total_chunks && (int)i < cap; i++) starts[i] = pl.frame_st[i];
+        *total_samples = pl.total_samples;
+        return (int)pl.total_chunks;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
+// reads chunk `index`; copies samples*K0 / samples*D floats out.  Returns samples (or -1).
+int mlggd_host_read_chunk(void *h, int index, int cv, float *in, float *targ) {
+    Interface *io = (Interface *)h;
+    try {
+        const int n = cv ? io->Readchunk_cv(index) : io->Readchunk(index);
+        const WorkPara *p = io->para;
+        memcpy(in, p->indata[0], (size_t)n * p->layersizes[0] * sizeof(float));
+        memcpy(targ, p->targ[0], (size_t)n * p->layersizes[io->numlayers - 1] * sizeof(float));
+        return n;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
+void mlggd_host_shuffle(void *h, int *vec, int len) { ((Interface *)h)->GetRandIndex(vec, len); }
+
+int mlggd_host_weights(void *h, int layer, float *w, float *b) {
+    Interface *io = (Interface *)h;
+    const WorkPara *p = io->para;
+    if (layer < 1 || layer >= io->numlayers) return -1;
+    memcpy(w, p->weights[layer], (size_t)p->layersizes[layer] * p->layersizes[layer - 1] * sizeof(float));
+    memcpy(b, p->bias[layer], (size_t)p->layersizes[layer] * sizeof(float));
+    return 0;
+}
+
+int mlggd_host_write_pfile(const char *path, const int *sent_lengths, int nsent, int num_features, const float *feat) {
+    try {
+        write_pfile(path, std::vector<int>(sent_lengths, sent_lengths + nsent), num_features, feat);
+        return 0;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
+}  // extern "C"
