@@ -306,7 +306,7 @@ static BiasJobs make_bias_jobs(mlggd_engine *e) {
 // BP_GPU.cu:308-440.
 static int run_step(mlggd_engine *e, const float *in_rows, const float *targ_rows) {
     const int L = e->L, B = e->B, Bp = e->Bp, b_tiles = Bp / 32;
-    const bool dp = e->world > 1;
+    const bool dp = e->comm != nullptr;  // a 1-rank communicator still takes the exchange path (tests)
     const int n_global = B * e->world;
     const float nf = (float)n_global;
     const float inv_n = 1.0f / n_global;  // DevVecMulNum(..., 1.0f/n_frames, ...), BP_GPU.cu:409,423

@@ -1,0 +1,176 @@
+"""GPU: committed goldens, the exchange (data-parallel) code path on a 1-rank RCCL
+communicator, and the BPtrain_Sigmoid executable end to end on synthetic pfiles."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import hostlib
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+HP = (0.1, 0.9, 1e-5)
+
+
+def relmax(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+@pytest.mark.parametrize("ml,beta", [(0, 2.0), (0, 1.0), (1, 2.0), (1, 1.2), (1, 0.9)])
+def test_tiny_goldens(pkg, synth, ml, beta):
+    g = np.load(os.path.join(GOLD, "tiny_net.npz"))
+    ls, B = [int(x) for x in g["layersizes"]], int(g["bunch"])
+    ws, bs = synth.make_weights(ls, seed=int(g["wseed"]))
+    inp, targ = synth.make_frames(int(g["frames"]), 5, 3, seed=int(g["dseed"]))
+    eng = pkg.BPGpu(1, 0, ls, B, *HP, ws, bs, beta, ml)
+    assert eng.train(inp, targ) == 3
+    key = "ml%d_b%s" % (ml, beta)
+    w, b = eng.returnWeights()
+    for l in range(4):
+        assert relmax(w[l], g["%s_W%d" % (key, l + 1)]) < 2e-5
+        assert relmax(b[l], g["%s_b%d" % (key, l + 1)]) < 2e-5
+        assert relmax(eng.debug_tensor("delta_w", l + 1), g["%s_dW%d" % (key, l + 1)]) < 2e-4
+    assert relmax(eng.debug_tensor("dedx", 4), g[key + "_dedx4"]) < 2e-4
+    cv = g[key + "_cv"]
+    sq, ab, ll = eng.cv_all(inp, targ)
+    assert abs(sq - cv[0]) <= 1e-4 * abs(cv[0]) and abs(ab - cv[1]) <= 1e-4 * abs(cv[1])
+    if ml:
+        assert relmax(eng.scalefactor(), g[key + "_alpha"]) < 1e-5
+        assert abs(ll - cv[2]) <= 1e-4 * abs(cv[2])
+    eng.close()
+
+
+@pytest.mark.parametrize("ml,beta", [(0, 2.0), (1, 1.2)])
+def test_baseline_goldens(pkg, synth, ml, beta):
+    g = np.load(os.path.join(GOLD, "baseline_net.npz"))
+    ls, B = synth.baseline_layersizes(), int(g["bunch"])
+    ws, bs = synth.make_weights(ls)
+    inp, targ = synth.make_frames(2 * B, 257, 11)
+    eng = pkg.BPGpu(1, 0, ls, B, *HP, ws, bs, beta, ml)
+    assert eng.train(inp, targ) == 2
+    key = "ml%d_b%s" % (ml, beta)
+    w, b = eng.returnWeights()
+    for l in range(4):
+        idx = g["%s_idx%d" % (key, l + 1)]
+        assert relmax(w[l].ravel()[idx], g["%s_Wsamp%d" % (key, l + 1)]) < 2e-5
+        dw = eng.debug_tensor("delta_w", l + 1)
+        assert relmax(dw.ravel()[idx], g["%s_dWsamp%d" % (key, l + 1)]) < 1e-3
+        s = g["%s_dWsum%d" % (key, l + 1)]
+        assert abs(dw.astype(np.float64).sum() - s[0]) <= 1e-4 * s[1]     # checksum of the whole tensor
+        assert relmax(b[l], g["%s_b%d" % (key, l + 1)]) < 2e-5
+    cin, ctarg = synth.make_frames(300, 257, 11, seed=77)
+    cv = g[key + "_cv"]
+    sq, ab, ll = eng.cv_all(cin, ctarg)
+    assert abs(sq - cv[0]) <= 1e-4 * abs(cv[0]) and abs(ab - cv[1]) <= 1e-4 * abs(cv[1])
+    if ml:
+        assert abs(ll - cv[2]) <= 1e-4 * abs(cv[2])
+    eng.close()
+
+
+@pytest.mark.parametrize("ml,beta", [(0, 2.0), (1, 1.2)])
+def test_exchange_path_on_one_rank_communicator(pkg, pyoracle, synth, ml, beta):
+    """mlggd_comm_init(world=1): RCCL is dlopen'ed, the step runs the unfused kernels
+    (gradient buffers, all-reduce on the comm stream, k_apply_update) -- must equal the oracle."""
+    ls, B = [257 * 3, 256, 160, 257], 64
+    ws, bs = synth.make_weights(ls, seed=5)
+    inp, targ = synth.make_frames(3 * B, 257, 3, seed=6)
+    eng = pkg.BPGpu(1, 0, ls, B, *HP, ws, bs, beta, ml)
+    eng.comm_init(pkg.comm_unique_id(), 1, 0)
+    ora = pyoracle.OracleNet(ls, B, *HP, beta, ml, ws, bs)
+    assert eng.train(inp, targ) == 3 and ora.train(inp, targ) == 3
+    we, be = eng.returnWeights()
+    wo, bo = ora.get_weights()
+    for l in range(3):
+        assert relmax(we[l], wo[l]) < 2e-5 and relmax(be[l], bo[l]) < 2e-5
+        assert relmax(eng.debug_tensor("grad_w", l + 1), ora.tensor("grad_w", l + 1)) < 3e-4
+    if ml:
+        assert relmax(eng.scalefactor(), ora.tensor("scalefactor")) < 1e-5
+    eng.close()
+
+
+def test_linearity_of_forward_at_full_size(pkg, synth):
+    """Size-independent property at BASELINE size: with one linear layer the network output is
+    linear in the input; f(a x1 + b x2) = a f(x1) + b f(x2) - (a+b-1) bias."""
+    ls = [2827, 257]
+    ws, bs = synth.make_weights(ls, seed=3)
+    bs = [np.linspace(-1, 1, 257).astype(np.float32)]
+    eng = pkg.BPGpu(1, 0, ls, 128, *HP, ws, bs, 2.0, 0)
+    x1, _ = synth.make_frames(300, 257, 11, seed=1)
+    x2, _ = synth.make_frames(300, 257, 11, seed=2)
+    f1, f2, f3 = eng.forward(x1), eng.forward(x2), eng.forward(0.5 * x1 - 2.0 * x2)
+    want = 0.5 * f1 - 2.0 * f2 + 2.5 * bs[0]
+    assert relmax(f3, want) < 1e-4
+    eng.close()
+
+
+def test_bptrain_sigmoid_executable(pkg, pyoracle, tmp_path):
+    """finetune.pl-style invocation of the drop-in binary on synthetic pfiles vs the same
+    pipeline driven from Python (real host IO code for the chunk/sample order + CPU oracle)."""
+    exe = os.path.join(hostlib.HOST, "BPtrain_Sigmoid")
+    subprocess.check_call(["make", "-C", hostlib.HOST, "-s"])
+    rng = np.random.default_rng(11)
+    dim, ctx, B = 20, 5, 16
+    lens = [int(x) for x in rng.integers(30, 90, 24)] + [3]
+    nfr = sum(lens)
+    noisy = rng.normal(3, 2, (nfr, dim)).astype(np.float32)
+    clean = (0.6 * noisy + rng.normal(0, 1, (nfr, dim))).astype(np.float32)
+    hostlib.write_pfile(str(tmp_path / "n.pfile"), lens, noisy)
+    hostlib.write_pfile(str(tmp_path / "c.pfile"), lens, clean)
+    hostlib.write_norm(str(tmp_path / "n.norm"), noisy.mean(0), 1.0 / noisy.std(0))
+    ls = [dim * ctx, 48, 40, dim]
+    subprocess.check_call([os.path.join(hostlib.HOST, "gen_rand_net"), "4", *map(str, ls), str(tmp_path),
+                           str(tmp_path / "init.wts"), "1", "2", "5"], stdout=subprocess.DEVNULL)
+    kv = dict(gpu_used=0, numlayers=4, layersizes=",".join(map(str, ls)), bunchsize=B, MLflag=1, shapefactor=1.2,
+              momentum=0.9, weightcost=1e-5, lrate=0.1, fea_dim=dim, fea_context=ctx, traincache=300,
+              init_randem_seed=27870775, targ_offset=2, initwts_file=tmp_path / "init.wts", norm_file=tmp_path / "n.norm",
+              fea_file=tmp_path / "n.pfile", targ_file=tmp_path / "c.pfile", outwts_file=tmp_path / "mlp.1.wts",
+              log_file=tmp_path / "mlp.1.log", train_sent_range="0-19", cv_sent_range="20-24", dropoutflag=0,
+              visible_omit=0.1, hid_omit=0.1)
+    res = subprocess.run([exe] + ["%s=%s" % (k, v) for k, v in kv.items()], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "all finish!" in res.stdout
+    log = open(tmp_path / "mlp.1.log").read()
+
+    # the same epoch from Python: real host IO code for order, CPU oracle for the math
+    io = hostlib.HostIO(**kv)
+    w0, b0 = hostlib.read_wts(str(tmp_path / "init.wts"), ls)
+    ora = pyoracle.OracleNet(ls, B, 0.1, 0.9, 1e-5, 1.2, 1, w0, b0)
+    starts, total = io.plan("0-19")
+    order = io.shuffle(len(starts))
+    assert len(starts) >= 3
+    for n, ci in enumerate(order):
+        inp, tg = io.read_chunk(ci, ls[0], dim, 300)
+        assert "Starting chunk %d of %d containing %d samples." % (n + 1, len(starts), len(inp)) in log
+        ora.train(inp, tg)
+    cvs, cvtotal = io.plan("20-24", cv=True)
+    sq = ab = ll = np.float32(0)
+    for ci in range(len(cvs)):
+        inp, tg = io.read_chunk(ci, ls[0], dim, 300, cv=True)
+        sq += np.float32(ora.cv_sqerr(inp, tg))
+        ab += np.float32(ora.cv_abserr(inp, tg))
+        ll += np.float32(ora.cv_loglik(inp, tg))
+    io.close()
+
+    ws, bs = hostlib.read_wts(str(tmp_path / "mlp.1.wts"), ls)
+    wo, bo = ora.get_weights()
+    for l in range(3):
+        assert relmax(ws[l], wo[l]) < 5e-5, l
+        assert relmax(bs[l], bo[l]) < 5e-5, l
+    got = [float(re.search(pat + r": (-?[\d.]+)", log).group(1)) for pat in
+           ("CV over. squared error", "CV over. square root squared error", "CV2 over. CV log likelihood")]
+    want = [float(sq) / cvtotal, float(ab) / cvtotal, float(ll) / cvtotal]
+    for g_, w_ in zip(got, want):
+        assert abs(g_ - w_) <= 1e-4 * abs(w_) + 1e-6, (got, want)
+    for line in ("Get pfile info over: Training data has %d frames, %d sentences." % (nfr, len(lens)), "Total cost time:",
+                 "Saving over.", "Starting CV."):
+        assert line in log
+
+    # errors: message in the log, non-zero exit status
+    kv["initwts_file"] = tmp_path / "missing.wts"
+    kv["log_file"] = tmp_path / "err.log"
+    res = subprocess.run([exe] + ["%s=%s" % (k, v) for k, v in kv.items()], capture_output=True, text=True, timeout=60)
+    assert res.returncode == 1 and "can not open initial weights file" in open(tmp_path / "err.log").read()

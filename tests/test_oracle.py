@@ -1,0 +1,147 @@
+"""CPU: the oracle against (a) the independent float64 model, (b) the committed goldens,
+(c) its own phase split (the data-parallel contract), (d) edge cases of BP_GPU::train."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from ref64 import Ref64
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = [(0, 2.0), (0, 1.0), (1, 2.0), (1, 1.2), (1, 0.9)]
+HP = (0.1, 0.9, 1e-5)
+
+
+def relmax(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+@pytest.mark.parametrize("ml,beta", CASES)
+def test_oracle_matches_float64_model(pyoracle, synth, ml, beta):
+    ls, B = [15, 8, 8, 8, 5], 8
+    ws, bs = synth.make_weights(ls, seed=3)
+    inp, targ = synth.make_frames(3 * B, 5, 3, seed=4)
+    o = pyoracle.OracleNet(ls, B, *HP, beta, ml, ws, bs)
+    r = Ref64(ls, *HP, beta, ml, ws, bs)
+    assert o.train(inp, targ) == 3
+    for i in range(3):
+        r.step(inp[i * B:(i + 1) * B], targ[i * B:(i + 1) * B])
+    w, b = o.get_weights()
+    for l in range(4):
+        assert relmax(w[l], r.W[l]) < 2e-6
+        assert relmax(b[l], r.b[l]) < 2e-5
+        assert relmax(o.tensor("delta_w", l + 1), r.dW[l]) < 2e-5
+    cv = r.cv(inp, targ)
+    assert abs(o.cv_sqerr(inp, targ) - cv["sqerr"]) < 1e-5 * cv["sqerr"]
+    assert abs(o.cv_abserr(inp, targ) - cv["abserr"]) < 1e-5 * cv["abserr"]
+    if ml:
+        assert relmax(o.tensor("scalefactor"), r.alpha) < 1e-5
+        # the reference's Gamma() is a polynomial (Gamma(1)=1.00001): compare loosely
+        assert abs(o.cv_loglik(inp, targ) - cv["loglik"]) < 2e-4 * abs(cv["loglik"])
+
+
+@pytest.mark.parametrize("ml,beta", CASES)
+def test_oracle_matches_tiny_goldens_bit_exact(pyoracle, synth, ml, beta):
+    g = np.load(os.path.join(GOLD, "tiny_net.npz"))
+    ls, B = [int(x) for x in g["layersizes"]], int(g["bunch"])
+    ws, bs = synth.make_weights(ls, seed=int(g["wseed"]))
+    inp, targ = synth.make_frames(int(g["frames"]), 5, 3, seed=int(g["dseed"]))
+    o = pyoracle.OracleNet(ls, B, *HP, beta, ml, ws, bs)
+    o.train(inp, targ)
+    key = "ml%d_b%s" % (ml, beta)
+    w, b = o.get_weights()
+    for l in range(4):
+        assert np.array_equal(w[l], g["%s_W%d" % (key, l + 1)])
+        assert np.array_equal(b[l], g["%s_b%d" % (key, l + 1)])
+        assert np.array_equal(o.tensor("delta_w", l + 1), g["%s_dW%d" % (key, l + 1)])
+    assert np.array_equal(o.tensor("dedx", 4, rows=B), g[key + "_dedx4"])
+    if ml:
+        assert np.array_equal(o.tensor("scalefactor"), g[key + "_alpha"])
+    cv = g[key + "_cv"]
+    assert o.cv_sqerr(inp, targ) == np.float32(cv[0])
+    assert o.cv_abserr(inp, targ) == np.float32(cv[1])
+
+
+def test_oracle_matches_baseline_goldens(pyoracle, synth):
+    g = np.load(os.path.join(GOLD, "baseline_net.npz"))
+    ls, B = synth.baseline_layersizes(), int(g["bunch"])
+    ws, bs = synth.make_weights(ls)
+    inp, targ = synth.make_frames(2 * B, 257, 11)
+    o = pyoracle.OracleNet(ls, B, *HP, 1.2, 1, ws, bs)
+    assert o.train(inp, targ) == 2
+    key = "ml1_b1.2"
+    w, b = o.get_weights()
+    for l in range(4):
+        idx = g["%s_idx%d" % (key, l + 1)]
+        assert np.array_equal(w[l].ravel()[idx], g["%s_Wsamp%d" % (key, l + 1)])
+        s = g["%s_Wsum%d" % (key, l + 1)]
+        assert abs(w[l].astype(np.float64).sum() - s[0]) <= 1e-9 * s[1]
+    assert np.array_equal(o.tensor("scalefactor"), g[key + "_alpha"])
+
+
+def test_gamma_table(pyoracle):
+    g = np.load(os.path.join(GOLD, "gamma.npz"))
+    for x, want in zip(g["x"], g["gamma"]):
+        got = pyoracle.gamma(float(x))
+        assert got == want
+        assert abs(got - math.gamma(float(x))) < 1e-4 * math.gamma(float(x))  # polynomial, BP_GPU.cu:597-607
+    assert pyoracle.gamma(0.0) == 0.0 and pyoracle.gamma(-1.0) == 0.0
+
+
+@pytest.mark.parametrize("ml,beta", [(0, 2.0), (1, 1.2)])
+def test_phase_split_equals_one_step(pyoracle, synth, ml, beta):
+    """Two 'ranks' of 16 frames each, gradients and column sums added, == one 32-frame step
+    (SURVEY.md 8e parity definition), up to summation order."""
+    ls, Bl = [33, 24, 17, 11], 16
+    ws, bs = synth.make_weights(ls, seed=8)
+    inp, targ = synth.make_frames(2 * Bl, 11, 3, seed=9)
+    single = pyoracle.OracleNet(ls, 2 * Bl, *HP, beta, ml, ws, bs)
+    single.train_bunch(inp, targ)
+    ranks = [pyoracle.OracleNet(ls, Bl, *HP, beta, ml, ws, bs) for _ in range(2)]
+    cols = []
+    for r, net in enumerate(ranks):
+        net.forward(inp[r * Bl:(r + 1) * Bl])
+        cols.append(net.loss_colsum(targ[r * Bl:(r + 1) * Bl]))
+    colsum = cols[0] + cols[1]
+    for r, net in enumerate(ranks):
+        net.loss_grad(targ[r * Bl:(r + 1) * Bl], 2 * Bl, colsum)
+        net.backward(inp[r * Bl:(r + 1) * Bl])
+    for l in (1, 2, 3):
+        g = ranks[0].tensor("grad_w", l) + ranks[1].tensor("grad_w", l)
+        assert relmax(g, single.tensor("grad_w", l)) < 1e-5
+        gb = ranks[0].tensor("grad_b", l) + ranks[1].tensor("grad_b", l)
+        assert relmax(gb, single.tensor("grad_b", l)) < 1e-5
+    if ml:
+        assert relmax(ranks[0].tensor("scalefactor"), single.tensor("scalefactor")) < 1e-6
+
+
+def test_train_skips_partial_bunch_and_empty(pyoracle, synth):
+    ls, B = [15, 8, 5], 8
+    ws, bs = synth.make_weights(ls, seed=1)
+    inp, targ = synth.make_frames(2 * B + 5, 5, 3)
+    a = pyoracle.OracleNet(ls, B, *HP, 2.0, 0, ws, bs)
+    b = pyoracle.OracleNet(ls, B, *HP, 2.0, 0, ws, bs)
+    assert a.train(inp, targ) == 2            # trailing 5 frames ignored, BP_GPU.cu:177-180
+    assert b.train(inp[:2 * B], targ[:2 * B]) == 2
+    for x, y in zip(a.get_weights()[0], b.get_weights()[0]):
+        assert np.array_equal(x, y)
+    assert a.train(inp[:0], targ[:0]) == 0
+    assert a.train(inp[:3], targ[:3]) == 0
+
+
+def test_zero_error_gradient_is_zero(pyoracle, synth):
+    """e == 0 branch of kernSubClean2 / kernfunc2 (DevFunc.cu:388-391,479-482)."""
+    ls, B = [6, 4], 4
+    ws = [np.zeros((6, 4), np.float32)]
+    bs = [np.zeros(4, np.float32)]
+    inp = np.ones((B, 6), np.float32)
+    targ = np.zeros((B, 4), np.float32)
+    targ[1:, :] = 1.0  # row 0 has e == 0 exactly, others e = -1
+    for ml, beta in CASES:
+        o = pyoracle.OracleNet(ls, B, *HP, beta, ml, ws, bs)
+        o.train_bunch(inp, targ)
+        d = o.tensor("dedx", 1, rows=B)
+        assert np.all(d[0] == 0) and np.all(np.isfinite(d)) and np.all(d[1:] < 0)
