@@ -98,9 +98,9 @@ def main():
 
     run_steps(args.warmup)
     eng.sync()
-    dw_layers = 0
     if not args.no_kernel_timing:
-        eng.profile_select("dw", 0, args.steps * (len(ls) - 1))
+        # HIP events around the dominant kernel's launches of every 8th step of the timed region
+        eng.profile_select("dw", 0, args.steps * (len(ls) - 1), stride=8)
     barrier()
     t0 = time.perf_counter()
     run_steps(args.steps)
@@ -116,15 +116,23 @@ def main():
     if not args.no_kernel_timing:
         us, nlaunch = eng.profile_read()
         eng.profile_select(None)
-        # the dominant kernel: k_dw (weight-gradient GEMM + fused SGD update), big-tile variant
-        big = [l for l in range(1, len(ls)) if ls[l] % 128 == 0]
-        fl = sum(eng.kernel_work("dw", l)[0] for l in big) / max(len(big), 1)
-        by = sum(eng.kernel_work("dw", l)[1] for l in big) / max(len(big), 1)
+        # the dominant kernel (largest share of the step in profiles/): k_dw<1,true>, the weight-gradient
+        # GEMM with the fused momentum / weight-decay update; mean over its launches (all layers)
+        nl = len(ls) - 1
+        fl = eng.kernel_work("dw", 0)[0] / nl
+        by = eng.kernel_work("dw", 0)[1] / nl
         if nlaunch > 0 and us > 0:
             ach = fl / (us * 1e-6) / 1e12
-            roofline = {"bound": "mfma", "kernel": "k_dw<2,2,fused> (dW GEMM + momentum/weight-decay update)",
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(pmc):  # HBM bytes per launch from rocprofv3 --pmc runs (profiles/README.md)
+                try:
+                    traffic = json.load(open(pmc)).get("k_dw", {}).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            roofline = {"bound": "mfma", "kernel": "k_dw<1,true> (dW GEMM + fused momentum/weight-decay update)",
                         "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                        "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
                         "mean_launch_us": round(us, 2), "launches_timed": nlaunch,
                         "algorithmic_flops_per_launch": fl, "algorithmic_bytes_per_launch": by,
                         "algorithmic_GBps": round(by / (us * 1e-6) / 1e9, 1)}

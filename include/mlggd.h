@@ -123,12 +123,13 @@ int mlggd_last_train_ms(mlggd_handle h, float *ms, int *steps);
 
 /* Kernel-class timing INSIDE a timed mlggd_train_resident region (bench.py's roofline
  * object): mlggd_profile_select brackets every launch of the named class ("transpose" "fwd"
- * "loss" "dx" "dw" "bias" "update"; layer 0 = all layers) with HIP events on the engine's
+ * "loss" "dx" "dw" "update"; layer 0 = all layers) with HIP events on the engine's
  * stream, up to max_launches; NULL/"" switches it off.  mlggd_profile_read syncs and returns
  * the mean launch duration in microseconds and the number of launches seen.
  * mlggd_kernel_work gives the algorithmic FLOPs / bytes of ONE launch of (class, layer)
  * (layer 0 = summed over layers), the figures DESIGN.md states per kernel. */
 int mlggd_profile_select(mlggd_handle h, const char *kernel_class, int layer, int max_launches);
+int mlggd_profile_stride(mlggd_handle h, int every_nth_step); /* bracket only every n-th step (default 1) */
 int mlggd_profile_read(mlggd_handle h, float *mean_usec, int *launches);
 int mlggd_kernel_work(mlggd_handle h, const char *kernel_class, int layer, double *flops, double *bytes);
 

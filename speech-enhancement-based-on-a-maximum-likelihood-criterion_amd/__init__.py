@@ -43,7 +43,7 @@ EXPORTS = [
     "mlggd_cv_loglik", "mlggd_cv_all", "mlggd_forward", "mlggd_get_weights", "mlggd_set_weights",
     "mlggd_get_scalefactor", "mlggd_set_scalefactor", "mlggd_set_lrate", "mlggd_gamma",
     "mlggd_debug_tensor", "mlggd_comm_unique_id", "mlggd_comm_init", "mlggd_last_train_ms",
-    "mlggd_profile_select", "mlggd_profile_read", "mlggd_kernel_work",
+    "mlggd_profile_select", "mlggd_profile_stride", "mlggd_profile_read", "mlggd_kernel_work",
     "mlggd_debug_stamp_select", "mlggd_debug_stamp_read",
 ]
 
@@ -94,6 +94,7 @@ def load():
     L.mlggd_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     L.mlggd_last_train_ms.argtypes = [C.c_void_p, _fp, C.POINTER(C.c_int)]
     L.mlggd_profile_select.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int]
+    L.mlggd_profile_stride.argtypes = [C.c_void_p, C.c_int]
     L.mlggd_profile_read.argtypes = [C.c_void_p, _fp, C.POINTER(C.c_int)]
     L.mlggd_kernel_work.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_double),
                                     C.POINTER(C.c_double)]
@@ -308,9 +309,10 @@ class BPGpu:
         _check(load().mlggd_comm_init(self._h, buf, int(world_size), int(rank)))
 
     # -- kernel-class timing
-    def profile_select(self, kernel_class, layer=0, max_launches=4096):
+    def profile_select(self, kernel_class, layer=0, max_launches=4096, stride=1):
         kc = kernel_class.encode() if kernel_class else None
         _check(load().mlggd_profile_select(self._h, kc, int(layer), int(max_launches)))
+        _check(load().mlggd_profile_stride(self._h, int(stride)))
 
     def profile_read(self):
         us, n = C.c_float(0), C.c_int(0)

@@ -92,8 +92,8 @@ static int rccl_load() {
     } while (0)
 
 // ------------------------------------------------------------------ engine state
-enum KernelClass { KC_TRANSPOSE = 0, KC_FWD, KC_LOSS, KC_DX, KC_DW, KC_DW_SMALL, KC_BIAS, KC_UPDATE, KC_COUNT };
-static const char *kKernelClassName[KC_COUNT] = {"transpose", "fwd", "loss", "dx", "dw", "dw_small", "bias", "update"};
+enum KernelClass { KC_TRANSPOSE = 0, KC_FWD, KC_LOSS, KC_DX, KC_DW, KC_UPDATE, KC_COUNT };
+static const char *kKernelClassName[KC_COUNT] = {"transpose", "fwd", "loss", "dx", "dw", "update"};
 
 struct mlggd_engine {
     mlggd_config cfg;
@@ -103,6 +103,12 @@ struct mlggd_engine {
     int B = 0, Bp = 0, D = 0, Dp = 0, K0 = 0;
     int device = 0;
     hipStream_t stream = nullptr, comm_stream = nullptr;
+    // weight-gradient/update kernels (HBM-bound) run on their own stream beside the MFMA-bound
+    // dX chain of the main stream; ev_dx[l] orders dw(l) after dX(l) (old-weights semantics),
+    // ev_upd orders the next step after the last update
+    hipStream_t dw_stream = nullptr;
+    hipEvent_t ev_dx[MLGGD_MAXLAYER] = {0}, ev_upd = nullptr;
+    int two_streams = 0;  // measured slower on MI355X (cross-stream event waits + contention): off
 
     float *W[MLGGD_MAXLAYER] = {0}, *dW[MLGGD_MAXLAYER] = {0};
     float *bias[MLGGD_MAXLAYER] = {0}, *dbias[MLGGD_MAXLAYER] = {0};
@@ -130,7 +136,7 @@ struct mlggd_engine {
     int last_steps = 0;
     bool timing_valid = false;
     // per-kernel-class profiling
-    int prof_class = -1, prof_layer = 0;
+    int prof_class = -1, prof_layer = 0, prof_stride = 1;
     std::vector<hipEvent_t> prof_ev;
     size_t prof_used = 0;
     double prof_flops = 0, prof_bytes = 0;
@@ -176,17 +182,19 @@ static int download_padded(float *dst, const float *src, int Np, int K, int N, h
 // ------------------------------------------------------------------ kernel launch plan
 struct ProfScope {
     mlggd_engine *e;
+    hipStream_t st;
     bool on;
-    ProfScope(mlggd_engine *eng, int cls, int layer) : e(eng), on(false) {
+    ProfScope(mlggd_engine *eng, int cls, int layer, hipStream_t s = nullptr)
+        : e(eng), st(s ? s : eng->stream), on(false) {
         if (e->prof_class == cls && (e->prof_layer == 0 || e->prof_layer == layer) &&
-            e->prof_used + 2 <= e->prof_ev.size()) {
+            e->step_counter % (unsigned)e->prof_stride == 0 && e->prof_used + 2 <= e->prof_ev.size()) {
             on = true;
-            hipEventRecord(e->prof_ev[e->prof_used], e->stream);
+            hipEventRecord(e->prof_ev[e->prof_used], st);
         }
     }
     ~ProfScope() {
         if (on) {
-            hipEventRecord(e->prof_ev[e->prof_used + 1], e->stream);
+            hipEventRecord(e->prof_ev[e->prof_used + 1], st);
             e->prof_used += 2;
         }
     }
@@ -259,12 +267,12 @@ static int run_forward(mlggd_engine *e, const float *in_rows, int frames, bool t
 }
 
 template <int T>
-static int launch_dw(mlggd_engine *e, int l, const float *in_rows, bool fused, float nf) {
+static int launch_dw(mlggd_engine *e, int l, const float *in_rows, bool fused, float nf, hipStream_t st) {
     const int Kp = e->lsp[l - 1], Np = e->lsp[l];
     const int k_wg = (Kp + 64 * T - 1) / (64 * T), n_wg = (Np + 64 * T - 1) / (64 * T);
     const float *A = (l == 1) ? in_rows : e->Y[l - 1];
     const int ldA = (l == 1) ? e->K0 : Kp;
-    const size_t lds = (size_t)2 * 128 * 64 * T * sizeof(float);
+    const size_t lds = (size_t)2 * (64 * T) * (64 * T) * sizeof(float);
     static bool attr_set[2] = {false, false};
     if (!attr_set[fused ? 1 : 0]) {
         const void *fn = fused ? (const void *)k_dw<T, true> : (const void *)k_dw<T, false>;
@@ -272,13 +280,14 @@ static int launch_dw(mlggd_engine *e, int l, const float *in_rows, bool fused, f
         attr_set[fused ? 1 : 0] = true;
     }
     if (fused)
-        hipLaunchKernelGGL((k_dw<T, true>), dim3(k_wg * n_wg), dim3(256), lds, e->stream, A, ldA, e->dEdX[l], e->W[l],
-                           e->dW[l], (float *)nullptr, e->ls[l - 1], Np, e->Bp, n_wg, nf, e->cfg.momentum,
-                           e->cfg.lrate, e->cfg.weightcost, stamps_for(e, KC_DW, l, k_wg * n_wg));
+        hipLaunchKernelGGL((k_dw<T, true>), dim3(k_wg * n_wg), dim3(256), lds, st, A, ldA, e->dEdX[l], e->W[l],
+                           e->dW[l], (float *)nullptr, e->bias[l], e->dbias[l], (float *)nullptr, e->ls[l - 1], e->ls[l], Np,
+                           e->B, e->Bp, n_wg, nf, e->cfg.momentum, e->cfg.lrate, e->cfg.weightcost,
+                           stamps_for(e, KC_DW, l, k_wg * n_wg));
     else
-        hipLaunchKernelGGL((k_dw<T, false>), dim3(k_wg * n_wg), dim3(256), lds, e->stream, A, ldA, e->dEdX[l], e->W[l],
-                           e->dW[l], e->G[l], e->ls[l - 1], Np, e->Bp, n_wg, nf, e->cfg.momentum, e->cfg.lrate,
-                           e->cfg.weightcost, (long long *)nullptr);
+        hipLaunchKernelGGL((k_dw<T, false>), dim3(k_wg * n_wg), dim3(256), lds, st, A, ldA, e->dEdX[l], e->W[l],
+                           e->dW[l], e->G[l], e->bias[l], e->dbias[l], e->gb[l], e->ls[l - 1], e->ls[l], Np, e->B, e->Bp, n_wg,
+                           nf, e->cfg.momentum, e->cfg.lrate, e->cfg.weightcost, (long long *)nullptr);
     return launch_check("k_dw");
 }
 
@@ -316,22 +325,26 @@ static int run_step(mlggd_engine *e, const float *in_rows, const float *targ_row
     {
         ProfScope ps(e, KC_LOSS, 0);
         const size_t lds = (size_t)(32 * (Bp + 1) + 32) * sizeof(float);
-        hipLaunchKernelGGL(k_loss_err, dim3((e->Dp / 32) * b_tiles), dim3(256), 0, e->stream, e->slab, e->S_out,
-                           e->bias[L - 1], targ_rows, B, e->D, e->Dp, Bp, e->cfg.shapefactor, ML == 1 ? 1 : 0,
-                           e->outT, e->eT, e->pT, b_tiles);
-        CHK(launch_check("k_loss_err"));
-        const float *colsum_in = nullptr;
-        if (dp && ML == 1) {
-            hipLaunchKernelGGL(k_colsum, dim3(e->Dp / 32), dim3(256), lds, e->stream, e->pT, B, Bp, e->colsum);
-            CHK(launch_check("k_colsum"));
-            NCCLCHK(g_rccl.AllReduce(e->colsum, e->colsum, (size_t)e->Dp, 7, 0, e->comm, e->stream));
-            colsum_in = e->colsum;
+        {
+            hipLaunchKernelGGL(k_loss_err, dim3((e->Dp / 32) * b_tiles), dim3(256), 0, e->stream, e->slab, e->S_out,
+                               e->bias[L - 1], targ_rows, B, e->D, e->Dp, Bp, e->cfg.shapefactor, ML == 1 ? 1 : 0,
+                               e->outT, e->eT, e->pT, b_tiles);
+            CHK(launch_check("k_loss_err"));
+            const float *colsum_in = nullptr;
+            if (dp && ML == 1) {
+                hipLaunchKernelGGL(k_colsum, dim3(e->Dp / 32), dim3(256), lds, e->stream, e->pT, B, Bp, e->colsum);
+                CHK(launch_check("k_colsum"));
+                NCCLCHK(g_rccl.AllReduce(e->colsum, e->colsum, (size_t)e->Dp, 7, 0, e->comm, e->stream));
+                colsum_in = e->colsum;
+            }
+            hipLaunchKernelGGL(k_loss_grad, dim3((e->Dp / 32) * b_tiles), dim3(256), lds, e->stream, e->eT, e->pT,
+                               colsum_in, B, e->D, e->Dp, Bp, e->cfg.shapefactor, ML, nf, inv_n, e->scalefactor,
+                               e->dEdXt[L - 1], e->dEdX[L - 1], b_tiles);
+            CHK(launch_check("k_loss_grad"));
         }
-        hipLaunchKernelGGL(k_loss_grad, dim3((e->Dp / 32) * b_tiles), dim3(256), lds, e->stream, e->eT, e->pT,
-                           colsum_in, B, e->D, e->Dp, Bp, e->cfg.shapefactor, ML, nf, inv_n, e->scalefactor,
-                           e->dEdXt[L - 1], e->dEdX[L - 1], b_tiles);
-        CHK(launch_check("k_loss_grad"));
     }
+    const bool two = e->two_streams != 0;
+    hipStream_t dws = two ? e->dw_stream : e->stream;
     for (int l = L - 1; l >= 1; l--) {
         const int Kp = e->lsp[l - 1], Np = e->lsp[l];
         if (l != 1) {
@@ -345,52 +358,48 @@ static int run_step(mlggd_engine *e, const float *in_rows, const float *targ_row
                                    e->Yt[l - 1], e->dEdXt[l - 1], e->dEdX[l - 1], Kp, Np, Bp, Kp / 32, b_tiles, st);
             CHK(launch_check("k_dx"));
         }
+        if (two) {  // dw(l) after dX(l): dEdX_l is final and W_l has been read (old weights)
+            HIPCHK(hipEventRecord(e->ev_dx[l], e->stream));
+            HIPCHK(hipStreamWaitEvent(dws, e->ev_dx[l], 0));
+        }
         {
             const long tiles128 = (long)((Kp + 127) / 128) * ((Np + 127) / 128);
             const bool big = e->dw_tile == 0 ? tiles128 >= 192 : e->dw_tile == 2;
-            ProfScope ps(e, big ? KC_DW : KC_DW_SMALL, l);
+            ProfScope ps(e, KC_DW, l, dws);
             if (big)
-                CHK(launch_dw<2>(e, l, in_rows, !dp, nf));
+                CHK(launch_dw<2>(e, l, in_rows, !dp, nf, dws));
             else
-                CHK(launch_dw<1>(e, l, in_rows, !dp, nf));
+                CHK(launch_dw<1>(e, l, in_rows, !dp, nf, dws));
         }
         if (dp) {
-            HIPCHK(hipEventRecord(e->ev_grad[l], e->stream));
+            HIPCHK(hipEventRecord(e->ev_grad[l], dws));
             HIPCHK(hipStreamWaitEvent(e->comm_stream, e->ev_grad[l], 0));
             NCCLCHK(g_rccl.AllReduce(e->G[l], e->G[l], (size_t)Kp * Np, 7, 0, e->comm, e->comm_stream));
             HIPCHK(hipEventRecord(e->ev_red[l], e->comm_stream));
         }
     }
-    {
-        ProfScope ps(e, KC_BIAS, 0);
-        BiasJobs jobs = make_bias_jobs(e);
-        if (!dp) {
-            hipLaunchKernelGGL(k_bias<true>, dim3((jobs.total + 63) / 64), dim3(64), 0, e->stream, jobs, B, nf,
-                               e->cfg.momentum, e->cfg.lrate);
-        } else {
-            hipLaunchKernelGGL(k_bias<false>, dim3((jobs.total + 63) / 64), dim3(64), 0, e->stream, jobs, B, nf,
-                               e->cfg.momentum, e->cfg.lrate);
-        }
-        CHK(launch_check("k_bias"));
-    }
     if (dp) {
-        HIPCHK(hipEventRecord(e->ev_bias, e->stream));
-        HIPCHK(hipStreamWaitEvent(e->comm_stream, e->ev_bias, 0));
+        // bias gradients were written by the dw kernels; ev_grad[1] is the last of them
+        HIPCHK(hipStreamWaitEvent(e->comm_stream, e->ev_grad[1], 0));
         NCCLCHK(g_rccl.AllReduce(e->gb_all, e->gb_all, e->gb_all_count, 7, 0, e->comm, e->comm_stream));
         HIPCHK(hipEventRecord(e->ev_bias_red, e->comm_stream));
         for (int l = L - 1; l >= 1; l--) {
-            HIPCHK(hipStreamWaitEvent(e->stream, e->ev_red[l], 0));
-            ProfScope ps(e, KC_UPDATE, l);
+            HIPCHK(hipStreamWaitEvent(dws, e->ev_red[l], 0));
+            ProfScope ps(e, KC_UPDATE, l, dws);
             const size_t n4 = (size_t)e->lsp[l - 1] * e->lsp[l] / 4;
-            hipLaunchKernelGGL(k_apply_update, dim3(2048), dim3(256), 0, e->stream, e->W[l], e->dW[l], e->G[l], n4, nf,
+            hipLaunchKernelGGL(k_apply_update, dim3(2048), dim3(256), 0, dws, e->W[l], e->dW[l], e->G[l], n4, nf,
                                e->cfg.momentum, e->cfg.lrate, e->cfg.weightcost);
             CHK(launch_check("k_apply_update"));
         }
-        HIPCHK(hipStreamWaitEvent(e->stream, e->ev_bias_red, 0));
+        HIPCHK(hipStreamWaitEvent(dws, e->ev_bias_red, 0));
         BiasJobs jobs = make_bias_jobs(e);
-        hipLaunchKernelGGL(k_bias_apply, dim3((jobs.total + 255) / 256), dim3(256), 0, e->stream, jobs, nf,
+        hipLaunchKernelGGL(k_bias_apply, dim3((jobs.total + 255) / 256), dim3(256), 0, dws, jobs, nf,
                            e->cfg.momentum, e->cfg.lrate);
         CHK(launch_check("k_bias_apply"));
+    }
+    if (two) {  // the next forward pass (and any host read-back on the main stream) waits for the updates
+        HIPCHK(hipEventRecord(e->ev_upd, dws));
+        HIPCHK(hipStreamWaitEvent(e->stream, e->ev_upd, 0));
     }
     e->step_counter++;
     return MLGGD_OK;
@@ -442,10 +451,14 @@ int mlggd_create(const mlggd_config *cfg, const float *const *weights, const flo
     if (const char *v = getenv("MLGGD_FWD_NW")) e->fwd_nw = atoi(v);
     if (const char *v = getenv("MLGGD_DX_NW")) e->dx_nw = atoi(v);
     if (const char *v = getenv("MLGGD_DW_TILE")) e->dw_tile = atoi(v);
+    if (const char *v = getenv("MLGGD_TWO_STREAMS")) e->two_streams = atoi(v);
     *out = e;  // so the caller can destroy on failure
 
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&e->dw_stream, hipStreamNonBlocking));
+    for (int l = 0; l < e->L; l++) HIPCHK(hipEventCreateWithFlags(&e->ev_dx[l], hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&e->ev_upd, hipEventDisableTiming));
     HIPCHK(hipEventCreate(&e->ev_t0));
     HIPCHK(hipEventCreate(&e->ev_t1));
 
@@ -493,6 +506,7 @@ int mlggd_destroy(mlggd_handle e) {
     hipSetDevice(e->device);
     if (e->stream) hipStreamSynchronize(e->stream);
     if (e->comm_stream) hipStreamSynchronize(e->comm_stream);
+    if (e->dw_stream) hipStreamSynchronize(e->dw_stream);
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
     for (void *p : e->allocs) hipFree(p);
     if (e->chunk_in) hipFree(e->chunk_in);
@@ -508,6 +522,10 @@ int mlggd_destroy(mlggd_handle e) {
     if (e->ev_t0) hipEventDestroy(e->ev_t0);
     if (e->ev_t1) hipEventDestroy(e->ev_t1);
     if (e->comm_stream) hipStreamDestroy(e->comm_stream);
+    for (int l = 0; l < MLGGD_MAXLAYER; l++)
+        if (e->ev_dx[l]) hipEventDestroy(e->ev_dx[l]);
+    if (e->ev_upd) hipEventDestroy(e->ev_upd);
+    if (e->dw_stream) hipStreamDestroy(e->dw_stream);
     if (e->stream) hipStreamDestroy(e->stream);
     delete e;
     return MLGGD_OK;
@@ -624,6 +642,7 @@ int mlggd_sync(mlggd_handle e) {
     if (!e) return fail(MLGGD_ERR_ARG, "NULL handle");
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->dw_stream) HIPCHK(hipStreamSynchronize(e->dw_stream));
     if (e->comm_stream) HIPCHK(hipStreamSynchronize(e->comm_stream));
     return MLGGD_OK;
 }
@@ -881,6 +900,12 @@ int mlggd_profile_select(mlggd_handle e, const char *kernel_class, int layer, in
         HIPCHK(hipEventCreate(&ev));
         e->prof_ev.push_back(ev);
     }
+    return MLGGD_OK;
+}
+
+int mlggd_profile_stride(mlggd_handle e, int every_nth_step) {
+    if (!e) return fail(MLGGD_ERR_ARG, "NULL handle");
+    e->prof_stride = every_nth_step < 1 ? 1 : every_nth_step;
     return MLGGD_OK;
 }
 

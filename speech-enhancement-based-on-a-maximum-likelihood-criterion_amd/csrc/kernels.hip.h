@@ -392,8 +392,10 @@ __device__ __forceinline__ float vget(float2 v, int t) { return t == 0 ? v.x : v
 template <int T, bool FUSED>
 __global__ __launch_bounds__(256) void k_dw(const float *__restrict__ Yrow, int ldA, const float *__restrict__ dEdX,
                                             float *__restrict__ Wt, float *__restrict__ delta,
-                                            float *__restrict__ G, int K, int Np, int Bp, int n_wg, float nf,
-                                            float mom, float lr, float wc, long long *stamps) {
+                                            float *__restrict__ G, float *__restrict__ bias,
+                                            float *__restrict__ dbias, float *__restrict__ gb, int K, int N, int Np,
+                                            int B, int Bp, int n_wg, float nf, float mom, float lr, float wc,
+                                            long long *stamps) {
     stamp(stamps, 0);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int TW = 64 * T;      // workgroup tile width (both dims)
@@ -403,7 +405,8 @@ __global__ __launch_bounds__(256) void k_dw(const float *__restrict__ Yrow, int 
     constexpr int NPASS = WT / RPP; // epilogue passes (4*T*T)
     constexpr int SQ = TW / 4;      // float4 per staged row
     constexpr int SRP = 256 / SQ;   // staged rows per pass
-    float *As = lds, *Bs = lds + 128 * TW;
+    constexpr int CH = 64 * T;      // frames staged per pass (LDS = 2*CH*TW floats: 32 KB / 128 KB)
+    float *As = lds, *Bs = lds + CH * TW;
     typedef typename VecT<T>::type vec_t;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
@@ -428,8 +431,9 @@ __global__ __launch_bounds__(256) void k_dw(const float *__restrict__ Yrow, int 
     float4 wreg[NPASS], dreg[NPASS];
 
     const int scol = tid % SQ, srow = tid / SQ;
-    for (int bc = 0; bc < Bp; bc += 128) {
-        const int rows = (Bp - bc < 128) ? (Bp - bc) : 128;
+    float bsum = 0.0f;  // bias gradient of column n0+tid (first k-tile row of workgroups only)
+    for (int bc = 0; bc < Bp; bc += CH) {
+        const int rows = (Bp - bc < CH) ? (Bp - bc) : CH;
         // ---- stage both operand tiles, 8 float4 per operand per batch
         for (int r0 = 0; r0 < rows; r0 += 8 * SRP) {
             float4 sa[8], sb[8];
@@ -450,6 +454,25 @@ __global__ __launch_bounds__(256) void k_dw(const float *__restrict__ Yrow, int 
         }
         __syncthreads();
         if (bc == 0) stamp(stamps, 1);
+        if (kt == 0 && tid < TW) {
+            // bias gradient: frames summed sequentially in fp32 (kernAccSumrow order,
+            // DevFunc.cu:267-285 <- BP_GPU.cu:434); the dEdX tile is in LDS anyway
+            const float *col = Bs + tid;
+            int b = 0;
+            const int bend = (B - bc < rows) ? (B - bc) : rows;
+            if (bc == 0 && bend > 0) {
+                bsum = col[0];
+                b = 1;
+            }
+            for (; b + 16 <= bend; b += 16) {
+                float v[16];
+#pragma unroll
+                for (int u = 0; u < 16; u++) v[u] = col[(b + u) * TW];
+#pragma unroll
+                for (int u = 0; u < 16; u++) bsum += v[u];
+            }
+            for (; b < bend; b++) bsum += col[b * TW];
+        }
         if (FUSED && bc == 0) {
             // W / delta prefetch: in flight during the whole MFMA loop
 #pragma unroll
@@ -484,6 +507,19 @@ __global__ __launch_bounds__(256) void k_dw(const float *__restrict__ Yrow, int 
     }
 
     stamp(stamps, 3);
+    if (kt == 0 && tid < TW) {
+        const int n = n0 + tid;
+        if (n < N) {
+            if (FUSED) {  // kernUpdatedelta with weightcost 0 + kernAccSum, BP_GPU.cu:435,437
+                const float bv = bias[n];
+                const float d = mom * dbias[n] - lr * (bsum / nf + 0.0f * bv);
+                dbias[n] = d;
+                bias[n] = d + 1.0f * bv;
+            } else {
+                gb[n] = bsum;
+            }
+        }
+    }
     // ---- epilogue: accumulators -> LDS (wave-private [WT][WT] tile) -> row-contiguous float4
     float *Tw = lds + wave * (WT * WT);
 #pragma unroll
@@ -549,10 +585,9 @@ __global__ __launch_bounds__(256) void k_apply_update(float *__restrict__ Wt, fl
 }
 
 // ---------------------------------------------------------------------------------------
-// Bias gradient + update for every layer in one launch: thread per unit, frames summed
-// sequentially in fp32 (kernAccSumrow order, DevFunc.cu:267-285 <- BP_GPU.cu:434), then
+// Bias update from the all-reduced bias gradients of every layer in one launch
+// (data-parallel path only; on one GPU the bias gradient and update live in k_dw):
 // kernUpdatedelta with weightcost 0 and kernAccSum (BP_GPU.cu:435,437).
-// FUSED=false stores the local sum to gb (data-parallel path).
 // ---------------------------------------------------------------------------------------
 struct BiasJob {
     const float *dEdX;  // [Bp][Np]
@@ -563,38 +598,6 @@ struct BiasJobs {
     BiasJob job[10];
     int njobs, total;
 };
-
-template <bool FUSED>
-__global__ __launch_bounds__(64) void k_bias(BiasJobs jobs, int B, float nf, float mom, float lr) {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= jobs.total) return;
-    int j = 0;
-#pragma unroll
-    for (int q = 1; q < 10; q++)
-        if (q < jobs.njobs && g >= jobs.job[q].first) j = q;
-    const BiasJob jb = jobs.job[j];
-    const int n = g - jb.first;
-    if (n >= jb.N) return;
-    const float *p = jb.dEdX + n;
-    float s = p[0];
-    int b = 1;
-    for (; b + 16 <= B; b += 16) {  // 16 independent loads in flight, adds stay in frame order
-        float v[16];
-#pragma unroll
-        for (int u = 0; u < 16; u++) v[u] = p[(size_t)(b + u) * jb.Np];
-#pragma unroll
-        for (int u = 0; u < 16; u++) s += v[u];
-    }
-    for (; b < B; b++) s += p[(size_t)b * jb.Np];
-    if (FUSED) {
-        const float bv = jb.bias[n];
-        const float d = mom * jb.dbias[n] - lr * (s / nf + 0.0f * bv);
-        jb.dbias[n] = d;
-        jb.bias[n] = d + 1.0f * bv;
-    } else {
-        jb.gb[n] = s;
-    }
-}
 
 __global__ __launch_bounds__(256) void k_bias_apply(BiasJobs jobs, float nf, float mom, float lr) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -635,6 +638,20 @@ __global__ __launch_bounds__(256) void k_transpose_in(const float *__restrict__ 
     }
 }
 
+// Sum of the S split-K slabs of one output element, slabs added in order s = 0..S-1.  All
+// loads are issued before the first add (one memory round trip instead of S).
+__device__ __forceinline__ float slab_sum(const float *__restrict__ slab, size_t o, size_t stride, int S) {
+    float v[8];
+#pragma unroll
+    for (int s = 0; s < 8; s++) v[s] = slab[(size_t)(s < S ? s : 0) * stride + o];
+    float x = v[0];
+#pragma unroll
+    for (int s = 1; s < 8; s++)
+        if (s < S) x += v[s];
+    for (int s = 8; s < S; s++) x += slab[(size_t)s * stride + o];
+    return x;
+}
+
 // ---------------------------------------------------------------------------------------
 // Output-layer loss, phase A (elementwise, one workgroup per 32(d) x 32(b) tile):
 //   out = bias + sum_s slab[s];  e = out - targ;  p = |e|^beta
@@ -661,9 +678,7 @@ __global__ __launch_bounds__(256) void k_loss_err(const float *__restrict__ slab
     for (int q = 0; q < 4; q++) {
         const int dl = ty + 8 * q, d = d0 + dl, b = b0 + tx;
         const size_t o = (size_t)d * Bp + b;
-        float x = slab[o];
-#pragma unroll 4
-        for (int s = 1; s < S; s++) x += slab[(size_t)s * slab_stride + o];
+        float x = slab_sum(slab, o, slab_stride, S);
         x = x + bias[d];
         float e = 0.0f, p = 0.0f;
         if (b < B && d < D) {
@@ -801,8 +816,7 @@ __global__ __launch_bounds__(256) void k_out_rowmajor(const float *__restrict__ 
     for (int q = 0; q < 4; q++) {
         const int d = d0 + ty + 8 * q;
         const size_t o = (size_t)d * Bp + b0 + tx;
-        float x = slab[o];
-        for (int s = 1; s < S; s++) x += slab[(size_t)s * Dp * Bp + o];
+        const float x = slab_sum(slab, o, (size_t)Dp * Bp, S);
         t[ty + 8 * q][tx] = x + bias[d];
     }
     __syncthreads();

@@ -27,9 +27,9 @@ for rnd in range(2):
         for _ in range(8): eng.train_resident(0, NB * B)
         eng.sync(); dt = (time.perf_counter() - t0) / (8 * NB)
         per = {}
-        for cls in ("fwd", "dx", "dw", "dw_small"):
+        for cls in ("fwd", "dx", "dw"):
             eng.profile_select(cls, 0, 4096); eng.train_resident(0, NB * B); us, n = eng.profile_read(); per[cls] = us
         eng.profile_select(None)
-        print("round %d %s: %.1f us/step  fwd %.1f dx %.1f dw %.1f dw_small %.1f us  (W2 relerr vs first %.1e)" %
-              (rnd, " ".join("%s=%s" % (k[6:], v) for k, v in cfg.items()), dt * 1e6, per["fwd"], per["dx"], per["dw"], per["dw_small"], err), flush=True)
+        print("round %d %s: %.1f us/step  fwd %.1f dx %.1f dw %.1f us  (W2 relerr vs first %.1e)" %
+              (rnd, " ".join("%s=%s" % (k[6:], v) for k, v in cfg.items()), dt * 1e6, per["fwd"], per["dx"], per["dw"], err), flush=True)
         eng.close()

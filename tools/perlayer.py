@@ -11,12 +11,11 @@ ws, bs = synth.make_weights(ls); inp, targ = synth.make_frames(NB * B, 257, 11)
 eng = pkg.BPGpu(1, 0, ls, B, 0.1, 0.9, 1e-5, ws, bs, 1.2 if ml else 2.0, ml)
 eng.load_chunk(inp, targ); eng.train_resident(0, NB * B); eng.sync()
 tot = 0.0
-for cls, layers in (("transpose", (0,)), ("fwd", (1, 2, 3, 4)), ("loss", (0,)), ("dx", (4, 3, 2)), ("dw", (4, 3, 2, 1)),
-                    ("dw_small", (4, 3, 2, 1)), ("bias", (0,))):
+for cls, layers in (("transpose", (0,)), ("fwd", (1, 2, 3, 4)), ("loss", (0,)), ("dx", (4, 3, 2)), ("dw", (4, 3, 2, 1))):
     for l in layers:
         eng.profile_select(cls, l, 4096); eng.train_resident(0, NB * B); us, n = eng.profile_read()
         if n:
-            f, by = eng.kernel_work(cls if cls != "dw_small" else "dw", l)
+            f, by = eng.kernel_work(cls, l)
             print("%-10s layer %d: %7.2f us  (%d launches)%s" % (cls, l, us, n,
                   "  %.1f TFLOP/s  %.0f GB/s alg" % (f / us / 1e6, by / us / 1e3) if f else ""))
             tot += us * n / NB

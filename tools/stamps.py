@@ -12,7 +12,7 @@ eng.load_chunk(inp, targ)
 eng.train_resident(0, 8 * B); eng.sync()
 names = {"fwd": ["mainloop", "reduce-sync", "epilogue"], "dx": ["mainloop", "reduce-sync", "epilogue"],
          "dw": ["stage", "prefetch-issue", "mfma", "acc->lds", "update+store"]}
-for cls, layers in (("fwd", (1, 2)), ("dx", (2, 3)), ("dw", (1, 2))):
+for cls, layers in (("fwd", (1, 2)), ("dx", (2, 3)), ("dw", (1, 2, 4))):
     for l in layers:
         for rep in range(2):
             eng.stamp_select(cls, l)
