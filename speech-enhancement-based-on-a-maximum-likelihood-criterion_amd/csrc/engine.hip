@@ -124,7 +124,7 @@ struct mlggd_engine {
     int chunk_frames = 0;
     unsigned step_counter = 0;
     // launch-plan knobs (defaults chosen from measurements; env overrides for A/B runs)
-    int fwd_nw = 8, dx_nw = 8, dw_tile = 1;  // dw_tile 0 = auto
+    int fwd_nw = 8, dx_nw = 8, dw_tile = 1, dw_persist = 1, dwp_per_cu = 2;  // dw_tile 0 = auto
 
     // data parallel
     int world = 1, rank = 0;
@@ -291,6 +291,33 @@ static int launch_dw(mlggd_engine *e, int l, const float *in_rows, bool fused, f
     return launch_check("k_dw");
 }
 
+// persistent pipelined dW (+update) kernel: Bp = 64*H
+template <int H>
+static int launch_dwp(mlggd_engine *e, int l, const float *in_rows, bool fused, float nf, hipStream_t st) {
+    const int Kp = e->lsp[l - 1], Np = e->lsp[l];
+    const int k_wg = (Kp + 63) / 64, n_wg = (Np + 63) / 64, ntiles = k_wg * n_wg;
+    const float *A = (l == 1) ? in_rows : e->Y[l - 1];
+    const int ldA = (l == 1) ? e->K0 : Kp;
+    const size_t lds = 2 * 8192 * sizeof(float);
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[fused ? 1 : 0]) {
+        const void *fn = fused ? (const void *)k_dwp<H, true> : (const void *)k_dwp<H, false>;
+        HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set[fused ? 1 : 0] = true;
+    }
+    int grid = 256 * (e->dwp_per_cu > 0 ? e->dwp_per_cu : 2);
+    if (grid > ntiles) grid = ntiles;
+    if (fused)
+        hipLaunchKernelGGL((k_dwp<H, true>), dim3(grid), dim3(256), lds, st, A, ldA, e->dEdX[l], e->W[l], e->dW[l],
+                           (float *)nullptr, e->bias[l], e->dbias[l], (float *)nullptr, e->ls[l - 1], e->ls[l], Kp, Np,
+                           e->B, n_wg, ntiles, nf, e->cfg.momentum, e->cfg.lrate, e->cfg.weightcost);
+    else
+        hipLaunchKernelGGL((k_dwp<H, false>), dim3(grid), dim3(256), lds, st, A, ldA, e->dEdX[l], e->W[l], e->dW[l],
+                           e->G[l], e->bias[l], e->dbias[l], e->gb[l], e->ls[l - 1], e->ls[l], Kp, Np, e->B, n_wg,
+                           ntiles, nf, e->cfg.momentum, e->cfg.lrate, e->cfg.weightcost);
+    return launch_check("k_dwp");
+}
+
 static BiasJobs make_bias_jobs(mlggd_engine *e) {
     BiasJobs jobs;
     memset(&jobs, 0, sizeof(jobs));
@@ -366,7 +393,13 @@ static int run_step(mlggd_engine *e, const float *in_rows, const float *targ_row
             const long tiles128 = (long)((Kp + 127) / 128) * ((Np + 127) / 128);
             const bool big = e->dw_tile == 0 ? tiles128 >= 192 : e->dw_tile == 2;
             ProfScope ps(e, KC_DW, l, dws);
-            if (big)
+            const int Hh = e->Bp / 64;
+            if (e->dw_persist && e->Bp % 64 == 0 && (Hh == 1 || Hh == 2 || Hh == 4 || Hh == 8)) {
+                if (Hh == 1) CHK(launch_dwp<1>(e, l, in_rows, !dp, nf, dws));
+                else if (Hh == 2) CHK(launch_dwp<2>(e, l, in_rows, !dp, nf, dws));
+                else if (Hh == 4) CHK(launch_dwp<4>(e, l, in_rows, !dp, nf, dws));
+                else CHK(launch_dwp<8>(e, l, in_rows, !dp, nf, dws));
+            } else if (big)
                 CHK(launch_dw<2>(e, l, in_rows, !dp, nf, dws));
             else
                 CHK(launch_dw<1>(e, l, in_rows, !dp, nf, dws));
@@ -452,6 +485,8 @@ int mlggd_create(const mlggd_config *cfg, const float *const *weights, const flo
     if (const char *v = getenv("MLGGD_DX_NW")) e->dx_nw = atoi(v);
     if (const char *v = getenv("MLGGD_DW_TILE")) e->dw_tile = atoi(v);
     if (const char *v = getenv("MLGGD_TWO_STREAMS")) e->two_streams = atoi(v);
+    if (const char *v = getenv("MLGGD_DW_PERSIST")) e->dw_persist = atoi(v);
+    if (const char *v = getenv("MLGGD_DWP_PER_CU")) e->dwp_per_cu = atoi(v);
     *out = e;  // so the caller can destroy on failure
 
     HIPCHK(hipSetDevice(e->device));

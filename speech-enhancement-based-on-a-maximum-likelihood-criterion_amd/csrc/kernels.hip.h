@@ -561,6 +561,233 @@ __global__ __launch_bounds__(256) void k_dw(const float *__restrict__ Yrow, int 
     stamp(stamps, 5);
 }
 
+// ---------------------------------------------------------------------------------------
+// Persistent, software-pipelined form of k_dw (same math, same outputs) for Bp = 64*H:
+// 64x64 tiles, <= 2 workgroups per CU, each walking tiles t = blockIdx.x, += gridDim.x.
+// A "unit" is one 64-frame slice of a tile's two operand tiles (32 KB of LDS, two buffers).
+// While unit u runs on the MFMA pipe, the 16-byte loads of unit u+1 (to registers) and 1/H
+// of the NEXT tile's W/delta tiles (to a second register set) are in flight, so HBM streams
+// continuously instead of in per-workgroup bursts (stage -> MFMA -> store lock-step of
+// k_dw: profiles/r01_phase_stamps.txt).  Every global access is an UNCONDITIONAL buffer
+// load/store whose out-of-range cases (pad rows k >= K, no next tile) are expressed through the
+// offset / an empty descriptor and dropped by the hardware range check: with no branch
+// around any memory instruction the compiler's s_waitcnt vmcnt(N) before the LDS write
+// leaves exactly the younger prefetch loads in flight.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void bstore4(float4 v, rsrc_t r, int voff) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), r, voff, 0, 0);
+}
+
+template <int H, bool FUSED>
+__global__ __launch_bounds__(256) void k_dwp(const float *__restrict__ Yrow, int ldA, const float *__restrict__ dEdX,
+                                             float *__restrict__ Wt, float *__restrict__ delta,
+                                             float *__restrict__ G, float *__restrict__ bias,
+                                             float *__restrict__ dbias, float *__restrict__ gb, int K, int N, int Kp,
+                                             int Np, int B, int n_wg, int ntiles, float nf, float mom, float lr,
+                                             float wc) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // [2 buffers][A | B][64][64]
+    constexpr int OOB = 0x7FFFFF00;  // byte offset beyond every descriptor: load -> 0, store dropped
+    constexpr int PPU = 8 / H;       // W/delta prefetch loads per unit (8 per tile and lane)
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
+    const int i = lane & 31, h5 = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int Bp = 64 * H;
+
+    const size_t szA = (size_t)Bp * ldA * 4, szB = (size_t)Bp * Np * 4, szW = (size_t)Kp * Np * 4;
+    const rsrc_t rA = make_rsrc(Yrow, szA), rB = make_rsrc(dEdX, szB);
+    const rsrc_t rW = make_rsrc(Wt, szW), rD = make_rsrc(delta, szW);
+    const rsrc_t rG = make_rsrc(G, FUSED ? 0 : szW);
+
+    const int scol = tid & 15, srow = tid >> 4;  // staging: 16 float4 per 64-float row, 16 rows per pass
+    const int ec = lane & 7, er = lane >> 3;     // epilogue: 8 float4 per 32-float wave-tile row
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+    float4 ra[4], rb[4];
+    float4 pw0[4], pd0[4], pw1[4], pd1[4];
+    float bsum = 0.0f;
+
+    int t = blockIdx.x;
+    if (t >= ntiles) return;
+    int k0 = (t / n_wg) * 64, n0 = (t % n_wg) * 64;
+
+#define DWP_LOAD_UNIT(RA, RB, K0, N0, HH)                                                       \
+    {                                                                                           \
+        _Pragma("unroll") for (int q = 0; q < 4; q++) {                                         \
+            const int row = 64 * (HH) + srow + 16 * q;                                          \
+            ra[q] = bload4(RA, (row * ldA + (K0) + 4 * scol) * 4, 0);                           \
+            rb[q] = bload4(RB, (row * Np + (N0) + 4 * scol) * 4, 0);                            \
+        }                                                                                       \
+    }
+#define DWP_WRITE_UNIT(BUF)                                                                     \
+    {                                                                                           \
+        float *as = lds + (BUF)*8192, *bs = as + 4096;                                          \
+        _Pragma("unroll") for (int q = 0; q < 4; q++) {                                         \
+            *reinterpret_cast<float4 *>(as + (srow + 16 * q) * 64 + 4 * scol) = ra[q];          \
+            *reinterpret_cast<float4 *>(bs + (srow + 16 * q) * 64 + 4 * scol) = rb[q];          \
+        }                                                                                       \
+    }
+    // voffset of this lane's float4 number IT of the wave tile at (K0, N0); OOB for pad rows
+#define DWP_OFF(K0, N0, IT)                                                                     \
+    ((((K0) + 32 * wm + er + 8 * (IT)) < K && ((N0) + 32 * wn + 4 * ec) < Np)                   \
+         ? (((K0) + 32 * wm + er + 8 * (IT)) * Np + (N0) + 32 * wn + 4 * ec) * 4                \
+         : OOB)
+#define DWP_PREFETCH(PW, PD, RW, RD, K0, N0, HH)                                                \
+    {                                                                                           \
+        if (FUSED) {                                                                            \
+            _Pragma("unroll") for (int jj = 0; jj < PPU; jj++) {                                \
+                const int j = (HH)*PPU + jj;                                                    \
+                if (j < 4) PW[j] = bload4(RW, DWP_OFF(K0, N0, j), 0);                           \
+                else PD[j - 4] = bload4(RD, DWP_OFF(K0, N0, j - 4), 0);                         \
+            }                                                                                   \
+        }                                                                                       \
+    }
+#define DWP_MFMA(BUF)                                                                           \
+    {                                                                                           \
+        const float *ap = lds + (BUF)*8192 + h5 * 64 + 32 * wm + i;                             \
+        const float *bp = lds + (BUF)*8192 + 4096 + h5 * 64 + 32 * wn + i;                      \
+        _Pragma("unroll") for (int p = 0; p < 32; p++) acc = mfma32(ap[p * 128], bp[p * 128], acc); \
+    }
+#define DWP_BIAS(BUF, HH)                                                                       \
+    {                                                                                           \
+        if (k0 == 0 && tid < 64) {                                                              \
+            const float *col = lds + (BUF)*8192 + 4096 + tid;                                   \
+            int bend = B - 64 * (HH);                                                           \
+            bend = bend < 64 ? bend : 64;                                                       \
+            int b = 0;                                                                          \
+            if ((HH) == 0 && bend > 0) {                                                        \
+                bsum = col[0];                                                                  \
+                b = 1;                                                                          \
+            }                                                                                   \
+            for (; b + 16 <= bend; b += 16) {                                                   \
+                float v[16];                                                                    \
+                _Pragma("unroll") for (int u = 0; u < 16; u++) v[u] = col[(b + u) * 64];        \
+                _Pragma("unroll") for (int u = 0; u < 16; u++) bsum += v[u];                    \
+            }                                                                                   \
+            for (; b < bend; b++) bsum += col[b * 64];                                          \
+        }                                                                                       \
+    }
+#define DWP_EPILOGUE(BUF, PW, PD)                                                               \
+    {                                                                                           \
+        if (k0 == 0 && tid < 64) {                                                              \
+            const int n = n0 + tid;                                                             \
+            if (n < N) {                                                                        \
+                if (FUSED) {                                                                    \
+                    const float bv = bias[n];                                                   \
+                    const float d = mom * dbias[n] - lr * (bsum / nf + 0.0f * bv);              \
+                    dbias[n] = d;                                                               \
+                    bias[n] = d + 1.0f * bv;                                                    \
+                } else {                                                                        \
+                    gb[n] = bsum;                                                               \
+                }                                                                               \
+            }                                                                                   \
+        }                                                                                       \
+        __syncthreads(); /* every wave is done reading BUF: reuse it as transposition scratch */ \
+        float *Tw = lds + (BUF)*8192 + wave * 1024;                                             \
+        _Pragma("unroll") for (int r = 0; r < 16; r++) Tw[acc_row(r, lane) * 32 + i] = acc[r];  \
+        __builtin_amdgcn_wave_barrier();                                                        \
+        _Pragma("unroll") for (int it = 0; it < 4; it++) {                                      \
+            const float4 g = *reinterpret_cast<const float4 *>(Tw + (er + 8 * it) * 32 + 4 * ec); \
+            const int off = DWP_OFF(k0, n0, it);                                                \
+            if (FUSED) {                                                                        \
+                const float4 w = PW[it];                                                        \
+                float4 d = PD[it];                                                              \
+                d.x = mom * d.x - lr * (g.x / nf + wc * w.x);                                   \
+                d.y = mom * d.y - lr * (g.y / nf + wc * w.y);                                   \
+                d.z = mom * d.z - lr * (g.z / nf + wc * w.z);                                   \
+                d.w = mom * d.w - lr * (g.w / nf + wc * w.w);                                   \
+                bstore4(d, rD, off);                                                            \
+                bstore4(make_float4(d.x + 1.0f * w.x, d.y + 1.0f * w.y, d.z + 1.0f * w.z, d.w + 1.0f * w.w), rW, off); \
+            } else {                                                                            \
+                bstore4(g, rG, off);                                                            \
+            }                                                                                   \
+        }                                                                                       \
+        _Pragma("unroll") for (int r = 0; r < 16; r++) acc[r] = 0.0f;                           \
+    }
+    // one tile: PWC/PDC = this tile's W/delta registers, PWN/PDN = the next tile's
+#define DWP_TILE(PWC, PDC, PWN, PDN)                                                            \
+    {                                                                                           \
+        const int tn = t + (int)gridDim.x;                                                      \
+        const bool has_next = tn < ntiles;                                                      \
+        const int k0n = has_next ? (tn / n_wg) * 64 : k0, n0n = has_next ? (tn % n_wg) * 64 : n0; \
+        const rsrc_t rAn = make_rsrc(Yrow, has_next ? szA : 0), rBn = make_rsrc(dEdX, has_next ? szB : 0); \
+        const rsrc_t rWn = make_rsrc(Wt, has_next ? szW : 0), rDn = make_rsrc(delta, has_next ? szW : 0);  \
+        _Pragma("unroll") for (int hh = 0; hh < H; hh++) {                                      \
+            const int buf = hh & 1;                                                             \
+            if (hh + 1 < H) DWP_LOAD_UNIT(rA, rB, k0, n0, hh + 1)                               \
+            else DWP_LOAD_UNIT(rAn, rBn, k0n, n0n, 0)                                           \
+            DWP_PREFETCH(PWN, PDN, rWn, rDn, k0n, n0n, hh)                                      \
+            DWP_BIAS(buf, hh)                                                                   \
+            DWP_MFMA(buf)                                                                       \
+            if (hh == H - 1) DWP_EPILOGUE(buf, PWC, PDC)                                        \
+            DWP_WRITE_UNIT(buf ^ 1)                                                             \
+            __syncthreads();                                                                    \
+        }                                                                                       \
+        if (!has_next) break;                                                                   \
+        t = tn;                                                                                 \
+        k0 = k0n;                                                                               \
+        n0 = n0n;                                                                               \
+    }
+
+    // prologue: first unit into buffer 0, this tile's W/delta into set 0
+    DWP_LOAD_UNIT(rA, rB, k0, n0, 0)
+    _Pragma("unroll") for (int hh = 0; hh < H; hh++) DWP_PREFETCH(pw0, pd0, rW, rD, k0, n0, hh)
+    DWP_WRITE_UNIT(0)
+    __syncthreads();
+    // For odd H the buffer parity flips from tile to tile; H is 1 or even here (H==1: the single
+    // unit always sits in buffer 0 because WRITE_UNIT(buf^1) of unit 0 targets buffer 1 ... so
+    // H==1 is handled by running two tiles per loop trip with swapped buffers).
+    for (;;) {
+        if (H == 1) {
+            // tile A from buffer 0 (next unit -> buffer 1), tile B from buffer 1 (next -> buffer 0)
+            {
+                const int tn = t + (int)gridDim.x;
+                const bool has_next = tn < ntiles;
+                const int k0n = has_next ? (tn / n_wg) * 64 : k0, n0n = has_next ? (tn % n_wg) * 64 : n0;
+                const rsrc_t rAn = make_rsrc(Yrow, has_next ? szA : 0), rBn = make_rsrc(dEdX, has_next ? szB : 0);
+                const rsrc_t rWn = make_rsrc(Wt, has_next ? szW : 0), rDn = make_rsrc(delta, has_next ? szW : 0);
+                DWP_LOAD_UNIT(rAn, rBn, k0n, n0n, 0)
+                DWP_PREFETCH(pw1, pd1, rWn, rDn, k0n, n0n, 0)
+                DWP_BIAS(0, 0)
+                DWP_MFMA(0)
+                DWP_EPILOGUE(0, pw0, pd0)
+                DWP_WRITE_UNIT(1)
+                __syncthreads();
+                if (!has_next) break;
+                t = tn; k0 = k0n; n0 = n0n;
+            }
+            {
+                const int tn = t + (int)gridDim.x;
+                const bool has_next = tn < ntiles;
+                const int k0n = has_next ? (tn / n_wg) * 64 : k0, n0n = has_next ? (tn % n_wg) * 64 : n0;
+                const rsrc_t rAn = make_rsrc(Yrow, has_next ? szA : 0), rBn = make_rsrc(dEdX, has_next ? szB : 0);
+                const rsrc_t rWn = make_rsrc(Wt, has_next ? szW : 0), rDn = make_rsrc(delta, has_next ? szW : 0);
+                DWP_LOAD_UNIT(rAn, rBn, k0n, n0n, 0)
+                DWP_PREFETCH(pw0, pd0, rWn, rDn, k0n, n0n, 0)
+                DWP_BIAS(1, 0)
+                DWP_MFMA(1)
+                DWP_EPILOGUE(1, pw1, pd1)
+                DWP_WRITE_UNIT(0)
+                __syncthreads();
+                if (!has_next) break;
+                t = tn; k0 = k0n; n0 = n0n;
+            }
+        } else {
+            DWP_TILE(pw0, pd0, pw1, pd1)
+            DWP_TILE(pw1, pd1, pw0, pd0)
+        }
+    }
+#undef DWP_LOAD_UNIT
+#undef DWP_WRITE_UNIT
+#undef DWP_OFF
+#undef DWP_PREFETCH
+#undef DWP_MFMA
+#undef DWP_BIAS
+#undef DWP_EPILOGUE
+#undef DWP_TILE
+}
+
 // Elementwise update from an (all-reduced) gradient, data-parallel path.  Pad entries have
 // G = delta = W = 0 and stay 0.  kernUpdatedelta + kernAccSum, DevFunc.cu:490-507,427-443.
 __global__ __launch_bounds__(256) void k_apply_update(float *__restrict__ Wt, float *__restrict__ delta,
