@@ -206,6 +206,77 @@ static int launch_check(const char *what) {
     return MLGGD_OK;
 }
 
+template <typename F>
+static int ensure_lds(F fn, size_t bytes) {
+    // kernels with > 64 KB of dynamic LDS need the attribute; cache by function address
+    static std::vector<const void *> done;
+    const void *key = (const void *)fn;
+    for (const void *d : done)
+        if (d == key) return MLGGD_OK;
+    HIPCHK(hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    done.push_back(key);
+    return MLGGD_OK;
+}
+
+static FwdArgs fwd_args(mlggd_engine *e, int l, float *Yrow_out) {
+    FwdArgs a;
+    a.W = e->W[l];
+    a.Yt_in = e->Yt[l - 1];
+    a.bias = e->bias[l];
+    a.Yt_out = e->Yt[l];
+    a.Y_out = Yrow_out;
+    a.slab = e->slab;
+    a.Kp = e->lsp[l - 1];
+    a.Np = e->lsp[l];
+    a.Bp = e->Bp;
+    a.N = e->ls[l];
+    a.n_tiles = e->lsp[l] / 32;
+    a.b_tiles = e->Bp / 32;
+    a.S = (l == e->L - 1) ? e->S_out : 1;
+    return a;
+}
+
+static DxArgs dx_args(mlggd_engine *e, int l) {
+    DxArgs a;
+    a.W = e->W[l];
+    a.dEdXt = e->dEdXt[l];
+    a.Yt_prev = e->Yt[l - 1];
+    a.dEdXt_prev = e->dEdXt[l - 1];
+    a.dEdX_prev = e->dEdX[l - 1];
+    a.Kp = e->lsp[l - 1];
+    a.Np = e->lsp[l];
+    a.Bp = e->Bp;
+    a.k_tiles = e->lsp[l - 1] / 32;
+    a.b_tiles = e->Bp / 32;
+    return a;
+}
+
+static DwpArgs dwp_args(mlggd_engine *e, int l, const float *in_rows, const float *Yrow_prev, float nf) {
+    DwpArgs a;
+    const int Kp = e->lsp[l - 1], Np = e->lsp[l];
+    a.Yrow = (l == 1) ? in_rows : Yrow_prev;
+    a.dEdX = e->dEdX[l];
+    a.Wt = e->W[l];
+    a.delta = e->dW[l];
+    a.G = e->G[l];
+    a.bias = e->bias[l];
+    a.dbias = e->dbias[l];
+    a.gb = e->gb[l];
+    a.ldA = (l == 1) ? e->K0 : Kp;
+    a.K = e->ls[l - 1];
+    a.N = e->ls[l];
+    a.Kp = Kp;
+    a.Np = Np;
+    a.B = e->B;
+    a.n_wg = (Np + 63) / 64;
+    a.ntiles = ((Kp + 63) / 64) * a.n_wg;
+    a.nf = nf;
+    a.mom = e->cfg.momentum;
+    a.lr = e->cfg.lrate;
+    a.wc = e->cfg.weightcost;
+    return a;
+}
+
 static int run_transpose(mlggd_engine *e, const float *in, int frames) {
     ProfScope ps(e, KC_TRANSPOSE, 0);
     const int b_tiles = e->Bp / 32, k_tiles = e->lsp[0] / 32;
@@ -240,20 +311,23 @@ static int run_forward(mlggd_engine *e, const float *in_rows, int frames, bool t
         }
         {
             ProfScope ps(e, KC_FWD, l);
+            FwdArgs fa = fwd_args(e, l, e->Y[l]);
             if (l != e->L - 1) {
                 long long *st = stamps_for(e, KC_FWD, l, n_tiles * b_tiles);
-#define LAUNCH_FWD(NW)                                                                                              \
-    hipLaunchKernelGGL((k_fwd<FWD_SIGMOID, NW>), dim3(n_tiles * b_tiles), dim3(64 * NW), 0, e->stream, e->W[l],       \
-                       e->Yt[l - 1], e->bias[l], e->Yt[l], e->Y[l], (float *)nullptr, Kp, Np, e->Bp, e->ls[l],        \
-                       n_tiles, b_tiles, 1, st)
-                if (e->fwd_nw == 16) LAUNCH_FWD(16);
-                else if (e->fwd_nw == 8) LAUNCH_FWD(8);
-                else LAUNCH_FWD(4);
+#define LAUNCH_FWD(NW)                                                                                      \
+    {                                                                                                       \
+        const size_t lds = fwd_lds_floats<NW>() * sizeof(float);                                            \
+        CHK(ensure_lds(k_fwd<FWD_SIGMOID, NW>, lds));                                                       \
+        hipLaunchKernelGGL((k_fwd<FWD_SIGMOID, NW>), dim3(n_tiles * b_tiles), dim3(64 * NW), lds, e->stream, fa, st); \
+    }
+                if (e->fwd_nw == 16) LAUNCH_FWD(16)
+                else if (e->fwd_nw == 8) LAUNCH_FWD(8)
+                else LAUNCH_FWD(4)
 #undef LAUNCH_FWD
             } else {
-                hipLaunchKernelGGL((k_fwd<FWD_SLAB, 4>), dim3(n_tiles * b_tiles * e->S_out), dim3(256), 0, e->stream,
-                                   e->W[l], e->Yt[l - 1], e->bias[l], (float *)nullptr, (float *)nullptr, e->slab, Kp,
-                                   Np, e->Bp, e->ls[l], n_tiles, b_tiles, e->S_out, (long long *)nullptr);
+                const size_t lds = fwd_lds_floats<4>() * sizeof(float);
+                hipLaunchKernelGGL((k_fwd<FWD_SLAB, 4>), dim3(n_tiles * b_tiles * e->S_out), dim3(256), lds, e->stream,
+                                   fa, (long long *)nullptr);
             }
         }
         CHK(launch_check("k_fwd"));
@@ -292,29 +366,22 @@ static int launch_dw(mlggd_engine *e, int l, const float *in_rows, bool fused, f
 }
 
 // persistent pipelined dW (+update) kernel: Bp = 64*H
+static int dwp_grid(mlggd_engine *e, int ntiles) {
+    int grid = 256 * (e->dwp_per_cu > 0 ? e->dwp_per_cu : 2);
+    return grid > ntiles ? ntiles : grid;
+}
 template <int H>
 static int launch_dwp(mlggd_engine *e, int l, const float *in_rows, bool fused, float nf, hipStream_t st) {
-    const int Kp = e->lsp[l - 1], Np = e->lsp[l];
-    const int k_wg = (Kp + 63) / 64, n_wg = (Np + 63) / 64, ntiles = k_wg * n_wg;
-    const float *A = (l == 1) ? in_rows : e->Y[l - 1];
-    const int ldA = (l == 1) ? e->K0 : Kp;
-    const size_t lds = 2 * 8192 * sizeof(float);
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[fused ? 1 : 0]) {
-        const void *fn = fused ? (const void *)k_dwp<H, true> : (const void *)k_dwp<H, false>;
-        HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set[fused ? 1 : 0] = true;
+    DwpArgs da = dwp_args(e, l, in_rows, e->Y[l - 1], nf);
+    const size_t lds = dwp_lds_floats() * sizeof(float);
+    const int grid = dwp_grid(e, da.ntiles);
+    if (fused) {
+        CHK(ensure_lds(k_dwp<H, true>, lds));
+        hipLaunchKernelGGL((k_dwp<H, true>), dim3(grid), dim3(256), lds, st, da);
+    } else {
+        CHK(ensure_lds(k_dwp<H, false>, lds));
+        hipLaunchKernelGGL((k_dwp<H, false>), dim3(grid), dim3(256), lds, st, da);
     }
-    int grid = 256 * (e->dwp_per_cu > 0 ? e->dwp_per_cu : 2);
-    if (grid > ntiles) grid = ntiles;
-    if (fused)
-        hipLaunchKernelGGL((k_dwp<H, true>), dim3(grid), dim3(256), lds, st, A, ldA, e->dEdX[l], e->W[l], e->dW[l],
-                           (float *)nullptr, e->bias[l], e->dbias[l], (float *)nullptr, e->ls[l - 1], e->ls[l], Kp, Np,
-                           e->B, n_wg, ntiles, nf, e->cfg.momentum, e->cfg.lrate, e->cfg.weightcost);
-    else
-        hipLaunchKernelGGL((k_dwp<H, false>), dim3(grid), dim3(256), lds, st, A, ldA, e->dEdX[l], e->W[l], e->dW[l],
-                           e->G[l], e->bias[l], e->dbias[l], e->gb[l], e->ls[l - 1], e->ls[l], Kp, Np, e->B, n_wg,
-                           ntiles, nf, e->cfg.momentum, e->cfg.lrate, e->cfg.weightcost);
     return launch_check("k_dwp");
 }
 
@@ -377,12 +444,16 @@ static int run_step(mlggd_engine *e, const float *in_rows, const float *targ_row
         if (l != 1) {
             ProfScope ps(e, KC_DX, l);
             long long *st = stamps_for(e, KC_DX, l, (Kp / 32) * b_tiles);
-            if (e->dx_nw == 8)
-                hipLaunchKernelGGL(k_dx<8>, dim3((Kp / 32) * b_tiles), dim3(512), 0, e->stream, e->W[l], e->dEdXt[l],
-                                   e->Yt[l - 1], e->dEdXt[l - 1], e->dEdX[l - 1], Kp, Np, Bp, Kp / 32, b_tiles, st);
-            else
-                hipLaunchKernelGGL(k_dx<4>, dim3((Kp / 32) * b_tiles), dim3(256), 0, e->stream, e->W[l], e->dEdXt[l],
-                                   e->Yt[l - 1], e->dEdXt[l - 1], e->dEdX[l - 1], Kp, Np, Bp, Kp / 32, b_tiles, st);
+            DxArgs xa = dx_args(e, l);
+            if (e->dx_nw == 8) {
+                const size_t lds = dx_lds_floats<8>() * sizeof(float);
+                CHK(ensure_lds(k_dx<8>, lds));
+                hipLaunchKernelGGL(k_dx<8>, dim3((Kp / 32) * b_tiles), dim3(512), lds, e->stream, xa, st);
+            } else {
+                const size_t lds = dx_lds_floats<4>() * sizeof(float);
+                CHK(ensure_lds(k_dx<4>, lds));
+                hipLaunchKernelGGL(k_dx<4>, dim3((Kp / 32) * b_tiles), dim3(256), lds, e->stream, xa, st);
+            }
             CHK(launch_check("k_dx"));
         }
         if (two) {  // dw(l) after dX(l): dEdX_l is final and W_l has been read (old weights)
@@ -997,20 +1068,24 @@ int mlggd_kernel_work(mlggd_handle e, const char *kernel_class, int layer, doubl
     if (!e || !kernel_class) return fail(MLGGD_ERR_ARG, "NULL argument");
     double f = 0, by = 0;
     const double B = e->B;
+    auto gemm = [&](const char *cls, int l, double &ff, double &bb) {
+        if (l < 1 || l >= e->L) return;
+        const double K = e->ls[l - 1], N = e->ls[l];
+        if (!strcmp(cls, "fwd")) {
+            ff += 2.0 * B * K * N;
+            bb += 4.0 * (K * N + B * K + 2 * B * N);
+        } else if (!strcmp(cls, "dx")) {
+            if (l == 1) return;
+            ff += 2.0 * B * K * N;
+            bb += 4.0 * (K * N + B * N + 3 * B * K);
+        } else if (!strcmp(cls, "dw")) {
+            ff += 2.0 * B * K * N;
+            bb += 4.0 * (4 * K * N + B * K + B * N);  // W, delta read + written
+        }
+    };
     for (int l = 1; l < e->L; l++) {
         if (layer != 0 && layer != l) continue;
-        const double K = e->ls[l - 1], N = e->ls[l];
-        if (!strcmp(kernel_class, "fwd")) {
-            f += 2.0 * B * K * N;
-            by += 4.0 * (K * N + B * K + 2 * B * N);
-        } else if (!strcmp(kernel_class, "dx")) {
-            if (l == 1) continue;
-            f += 2.0 * B * K * N;
-            by += 4.0 * (K * N + B * N + 3 * B * K);
-        } else if (!strcmp(kernel_class, "dw")) {
-            f += 2.0 * B * K * N;
-            by += 4.0 * (4 * K * N + B * K + B * N);  // W,delta read + written
-        }
+        gemm(kernel_class, l, f, by);
     }
     if (flops) *flops = f;
     if (bytes) *bytes = by;

@@ -60,9 +60,9 @@ __device__ __forceinline__ float4 bload4(rsrc_t r, int voff, int soff) {
 }
 // Diagnostic phase stamps (100 MHz wall clock).  `stamps` is nullptr in every normal launch;
 // mlggd_debug_stamp_select() passes a buffer for ONE launch and the values go nowhere else.
-__device__ __forceinline__ void stamp(long long *stamps, int slot) {
+__device__ __forceinline__ void stamp(long long *stamps, int slot, int bid = -1) {
     if (stamps != nullptr && threadIdx.x == 0) {
-        stamps[(size_t)blockIdx.x * 8 + slot] = (long long)__builtin_amdgcn_s_memrealtime();
+        stamps[(size_t)(bid < 0 ? (int)blockIdx.x : bid) * 8 + slot] = (long long)__builtin_amdgcn_s_memrealtime();
     }
 }
 // wave index as a provably wave-uniform value (scalar branches, exact s_waitcnt counts)
@@ -87,19 +87,26 @@ __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane
 // ---------------------------------------------------------------------------------------
 enum { FWD_SIGMOID = 0, FWD_SLAB = 1 };
 
+struct FwdArgs {
+    const float *W, *Yt_in, *bias;
+    float *Yt_out, *Y_out, *slab;
+    int Kp, Np, Bp, N, n_tiles, b_tiles, S;
+};
+// LDS floats needed by fwd_body<.,NW>: staging/reduction tiles + the 32x33 transposition tile
+template <int NW> constexpr int fwd_lds_floats() { return NW * 2048 + 32 * 33; }
+
 template <int MODE, int NW>
-__global__ __launch_bounds__(64 * NW) void k_fwd(const float *__restrict__ W, const float *__restrict__ Yt_in,
-                                                 const float *__restrict__ bias, float *__restrict__ Yt_out,
-                                                 float *__restrict__ Y_out, float *__restrict__ slab, int Kp, int Np,
-                                                 int Bp, int N, int n_tiles, int b_tiles, int S, long long *stamps) {
+__device__ __forceinline__ void fwd_body(const FwdArgs &A, const int bid, float *smem, long long *stamps) {
+    const float *__restrict__ W = A.W, *__restrict__ Yt_in = A.Yt_in, *__restrict__ bias = A.bias;
+    float *__restrict__ Yt_out = A.Yt_out, *__restrict__ Y_out = A.Y_out, *__restrict__ slab = A.slab;
+    const int Kp = A.Kp, Np = A.Np, Bp = A.Bp, N = A.N, n_tiles = A.n_tiles, b_tiles = A.b_tiles, S = A.S;
     // per wave: [32 k rows][32] of W then [32 k rows][32] of Yt (8 KB); the cross-wave
     // reduction buffer red[NW][1024] aliases the same storage after the main loop
-    __shared__ __attribute__((aligned(16))) float smem[NW * 2048];
-    __shared__ float tileT[32][33];
-    stamp(stamps, 0);
+    float(*tileT)[33] = reinterpret_cast<float(*)[33]>(smem + NW * 2048);
+    stamp(stamps, 0, bid);
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
     const int i = lane & 31, h = lane >> 5;
-    int id = blockIdx.x, s = 0;
+    int id = bid, s = 0;
     if (MODE == FWD_SLAB) {
         s = id % S;
         id /= S;
@@ -175,14 +182,14 @@ __global__ __launch_bounds__(64 * NW) void k_fwd(const float *__restrict__ W, co
 #undef FWD_WRITE
 #undef FWD_COMPUTE
 
-    stamp(stamps, 1);
+    stamp(stamps, 1, bid);
     // cross-wave reduction through LDS (aliases the staging tiles: wait for every wave)
     __syncthreads();
     float(*red)[1024] = reinterpret_cast<float(*)[1024]>(smem);
 #pragma unroll
     for (int r = 0; r < 16; r++) red[wave][acc_row(r, lane) * 32 + i] = acc[r];
     __syncthreads();
-    stamp(stamps, 2);
+    stamp(stamps, 2, bid);
     // 1024 tile elements over 64*NW threads; partial sums added in wave order (deterministic)
     constexpr int NT = 64 * NW, EPT = 1024 / NT > 0 ? 1024 / NT : 1;
     float v[EPT];
@@ -222,7 +229,7 @@ __global__ __launch_bounds__(64 * NW) void k_fwd(const float *__restrict__ W, co
             if (e < 1024) Y_out[(size_t)(b0 + bl) * Np + n0 + nl] = tileT[bl][nl];
         }
     }
-    stamp(stamps, 3);
+    stamp(stamps, 3, bid);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -237,20 +244,26 @@ __global__ __launch_bounds__(64 * NW) void k_fwd(const float *__restrict__ W, co
 // conflict-free ds_read_b64 giving two consecutive n per lane).
 // ---------------------------------------------------------------------------------------
 #define DX_LDW 66
+struct DxArgs {
+    const float *W, *dEdXt, *Yt_prev;
+    float *dEdXt_prev, *dEdX_prev;
+    int Kp, Np, Bp, k_tiles, b_tiles;
+};
+template <int NW> constexpr int dx_lds_floats() { return NW * (32 * DX_LDW + 2048) + 32 * 33; }
+
 template <int NW>
-__global__ __launch_bounds__(64 * NW) void k_dx(const float *__restrict__ W, const float *__restrict__ dEdXt,
-                                                const float *__restrict__ Yt_prev, float *__restrict__ dEdXt_prev,
-                                                float *__restrict__ dEdX_prev, int Kp, int Np, int Bp, int k_tiles,
-                                                int b_tiles, long long *stamps) {
+__device__ __forceinline__ void dx_body(const DxArgs &A, const int bid, float *smem, long long *stamps) {
+    const float *__restrict__ W = A.W, *__restrict__ dEdXt = A.dEdXt, *__restrict__ Yt_prev = A.Yt_prev;
+    float *__restrict__ dEdXt_prev = A.dEdXt_prev, *__restrict__ dEdX_prev = A.dEdX_prev;
+    const int Kp = A.Kp, Np = A.Np, Bp = A.Bp, k_tiles = A.k_tiles, b_tiles = A.b_tiles;
     // per wave: W piece [32][66] (2112 floats) + dEdXt piece [64 n][32] (2048 floats)
     constexpr int WSZ = 32 * DX_LDW, STG = WSZ + 2048;
-    __shared__ __attribute__((aligned(16))) float smem[NW * STG];
-    __shared__ float tileT[32][33];
-    stamp(stamps, 0);
+    float(*tileT)[33] = reinterpret_cast<float(*)[33]>(smem + NW * STG);
+    stamp(stamps, 0, bid);
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
     const int i = lane & 31, h = lane >> 5;
     int kt, bt;
-    tile_of_block(blockIdx.x, k_tiles, b_tiles, kt, bt);
+    tile_of_block(bid, k_tiles, b_tiles, kt, bt);
     const int k0 = kt * 32, b0 = bt * 32;
 
     const int Q = Np >> 2;             // quads of 4 consecutive n
@@ -330,13 +343,13 @@ __global__ __launch_bounds__(64 * NW) void k_dx(const float *__restrict__ W, con
 #undef DX_WRITE
 #undef DX_COMPUTE
 
-    stamp(stamps, 1);
+    stamp(stamps, 1, bid);
     __syncthreads();
     float(*red)[1024] = reinterpret_cast<float(*)[1024]>(smem);
 #pragma unroll
     for (int r = 0; r < 16; r++) red[wave][acc_row(r, lane) * 32 + i] = acc[r];
     __syncthreads();
-    stamp(stamps, 2);
+    stamp(stamps, 2, bid);
     constexpr int NT = 64 * NW, EPT = 1024 / NT > 0 ? 1024 / NT : 1;
 #pragma unroll
     for (int q = 0; q < EPT; q++) {
@@ -358,7 +371,7 @@ __global__ __launch_bounds__(64 * NW) void k_dx(const float *__restrict__ W, con
         const int e = tid + NT * q, bl = e >> 5, kl = e & 31;
         if (e < 1024) dEdX_prev[(size_t)(b0 + bl) * Kp + k0 + kl] = tileT[bl][kl];
     }
-    stamp(stamps, 3);
+    stamp(stamps, 3, bid);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -578,14 +591,23 @@ __device__ __forceinline__ void bstore4(float4 v, rsrc_t r, int voff) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), r, voff, 0, 0);
 }
 
+struct DwpArgs {
+    const float *Yrow, *dEdX;
+    float *Wt, *delta, *G, *bias, *dbias, *gb;
+    int ldA, K, N, Kp, Np, B, n_wg, ntiles;
+    float nf, mom, lr, wc;
+};
+constexpr int dwp_lds_floats() { return 2 * 8192; }
+
+// bid / nblocks: this workgroup's index and the number of workgroups walking the tiles (the
+// body is written so that it could share a launch with other work)
 template <int H, bool FUSED>
-__global__ __launch_bounds__(256) void k_dwp(const float *__restrict__ Yrow, int ldA, const float *__restrict__ dEdX,
-                                             float *__restrict__ Wt, float *__restrict__ delta,
-                                             float *__restrict__ G, float *__restrict__ bias,
-                                             float *__restrict__ dbias, float *__restrict__ gb, int K, int N, int Kp,
-                                             int Np, int B, int n_wg, int ntiles, float nf, float mom, float lr,
-                                             float wc) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];  // [2 buffers][A | B][64][64]
+__device__ __forceinline__ void dwp_body(const DwpArgs &A, const int bid, const int nblocks, float *lds) {
+    const float *__restrict__ Yrow = A.Yrow, *__restrict__ dEdX = A.dEdX;
+    float *__restrict__ Wt = A.Wt, *__restrict__ delta = A.delta, *__restrict__ G = A.G;
+    float *__restrict__ bias = A.bias, *__restrict__ dbias = A.dbias, *__restrict__ gb = A.gb;
+    const int ldA = A.ldA, K = A.K, N = A.N, Kp = A.Kp, Np = A.Np, B = A.B, n_wg = A.n_wg, ntiles = A.ntiles;
+    const float nf = A.nf, mom = A.mom, lr = A.lr, wc = A.wc;
     constexpr int OOB = 0x7FFFFF00;  // byte offset beyond every descriptor: load -> 0, store dropped
     constexpr int PPU = 8 / H;       // W/delta prefetch loads per unit (8 per tile and lane)
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
@@ -608,7 +630,7 @@ __global__ __launch_bounds__(256) void k_dwp(const float *__restrict__ Yrow, int
     float4 pw0[4], pd0[4], pw1[4], pd1[4];
     float bsum = 0.0f;
 
-    int t = blockIdx.x;
+    int t = bid;
     if (t >= ntiles) return;
     int k0 = (t / n_wg) * 64, n0 = (t % n_wg) * 64;
 
@@ -708,7 +730,7 @@ __global__ __launch_bounds__(256) void k_dwp(const float *__restrict__ Yrow, int
     // one tile: PWC/PDC = this tile's W/delta registers, PWN/PDN = the next tile's
 #define DWP_TILE(PWC, PDC, PWN, PDN)                                                            \
     {                                                                                           \
-        const int tn = t + (int)gridDim.x;                                                      \
+        const int tn = t + nblocks;                                                      \
         const bool has_next = tn < ntiles;                                                      \
         const int k0n = has_next ? (tn / n_wg) * 64 : k0, n0n = has_next ? (tn % n_wg) * 64 : n0; \
         const rsrc_t rAn = make_rsrc(Yrow, has_next ? szA : 0), rBn = make_rsrc(dEdX, has_next ? szB : 0); \
@@ -742,7 +764,7 @@ __global__ __launch_bounds__(256) void k_dwp(const float *__restrict__ Yrow, int
         if (H == 1) {
             // tile A from buffer 0 (next unit -> buffer 1), tile B from buffer 1 (next -> buffer 0)
             {
-                const int tn = t + (int)gridDim.x;
+                const int tn = t + nblocks;
                 const bool has_next = tn < ntiles;
                 const int k0n = has_next ? (tn / n_wg) * 64 : k0, n0n = has_next ? (tn % n_wg) * 64 : n0;
                 const rsrc_t rAn = make_rsrc(Yrow, has_next ? szA : 0), rBn = make_rsrc(dEdX, has_next ? szB : 0);
@@ -758,7 +780,7 @@ __global__ __launch_bounds__(256) void k_dwp(const float *__restrict__ Yrow, int
                 t = tn; k0 = k0n; n0 = n0n;
             }
             {
-                const int tn = t + (int)gridDim.x;
+                const int tn = t + nblocks;
                 const bool has_next = tn < ntiles;
                 const int k0n = has_next ? (tn / n_wg) * 64 : k0, n0n = has_next ? (tn % n_wg) * 64 : n0;
                 const rsrc_t rAn = make_rsrc(Yrow, has_next ? szA : 0), rBn = make_rsrc(dEdX, has_next ? szB : 0);
@@ -788,6 +810,28 @@ __global__ __launch_bounds__(256) void k_dwp(const float *__restrict__ Yrow, int
 #undef DWP_TILE
 }
 
+// ---------------------------------------------------------------------------------------
+// Launch wrappers.  The bodies above are __device__ functions taking an explicit block id
+// and LDS base so that several of them can share one launch.  That was tried -- dX(l) together
+// with dW(l+1), and forward_1 of the next minibatch with dW(2), as two roles of one grid so an
+// MFMA-bound and an HBM-bound body share every CU -- and measured at exactly the sum of the
+// separate launches (they contend in the CU's memory pipeline instead of complementing each
+// other), so only the stand-alone kernels remain.
+// ---------------------------------------------------------------------------------------
+extern __shared__ __attribute__((aligned(16))) float g_dyn_lds[];
+
+template <int MODE, int NW>
+__global__ __launch_bounds__(64 * NW) void k_fwd(FwdArgs A, long long *stamps) {
+    fwd_body<MODE, NW>(A, (int)blockIdx.x, g_dyn_lds, stamps);
+}
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_dx(DxArgs A, long long *stamps) {
+    dx_body<NW>(A, (int)blockIdx.x, g_dyn_lds, stamps);
+}
+template <int H, bool FUSED>
+__global__ __launch_bounds__(256) void k_dwp(DwpArgs A) {
+    dwp_body<H, FUSED>(A, (int)blockIdx.x, (int)gridDim.x, g_dyn_lds);
+}
 // Elementwise update from an (all-reduced) gradient, data-parallel path.  Pad entries have
 // G = delta = W = 0 and stay 0.  kernUpdatedelta + kernAccSum, DevFunc.cu:490-507,427-443.
 __global__ __launch_bounds__(256) void k_apply_update(float *__restrict__ Wt, float *__restrict__ delta,
