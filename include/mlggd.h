@@ -94,6 +94,28 @@ int mlggd_cv_all(mlggd_handle h, int n_frames, const float *in, const float *tar
 /* cv_bunch_single over a whole chunk: out[n_frames][D] network outputs (forward only). */
 int mlggd_forward(mlggd_handle h, int n_frames, const float *in, float *out);
 
+/* ---- input pipeline on the device (no counterpart in the reference, which
+ * context-expands every chunk on one host thread, Interface.cc:778-785, and uploads the 11x
+ * larger matrix, BP_GPU.cu:163-164).  A sample is a window of fea_context CONSECUTIVE frames,
+ * i.e. a contiguous slice of the normalised frame stream, so the caller uploads the chunk's
+ * frames once -- feat [n_frames][layersizes[0]/fea_context], targ [n_frames][D] -- plus, for
+ * every sample ROW (in the shuffled row order Readchunk would have produced), the index of its
+ * first frame; sample i's target is frame first_frame[i] + targ_offset.  Rows are gathered by
+ * the input-staging kernel; results are bit-identical to the expanded path.
+ * After mlggd_load_frames, mlggd_train_resident indexes SAMPLES of this chunk. */
+int mlggd_load_frames(mlggd_handle h, int n_frames, int fea_context, const float *feat, const float *targ,
+                      int n_samples, const int32_t *first_frame, int targ_offset);
+int mlggd_train_frames(mlggd_handle h, int n_frames, int fea_context, const float *feat, const float *targ,
+                       int n_samples, const int32_t *first_frame, int targ_offset, int *bunches_trained);
+int mlggd_cv_all_frames(mlggd_handle h, int n_frames, int fea_context, const float *feat, const float *targ,
+                        int n_samples, const int32_t *first_frame, int targ_offset, float *sqerr, float *abserr,
+                        float *loglik);
+int mlggd_forward_frames(mlggd_handle h, int n_frames, int fea_context, const float *feat, int n_samples,
+                         const int32_t *first_frame, float *out);
+/* pinned host memory for chunk buffers (optional; faster H2D than pageable memory) */
+int mlggd_alloc_pinned(size_t bytes, void **out);
+int mlggd_free_pinned(void *p);
+
 /* ---- state: BP_GPU::returnWeights (BP_GPU.cu:514-525) and dev.scalefactor (:287) ---- */
 int mlggd_get_weights(mlggd_handle h, float *const *weights, float *const *bias);
 int mlggd_set_weights(mlggd_handle h, const float *const *weights, const float *const *bias);

@@ -45,6 +45,8 @@ EXPORTS = [
     "mlggd_debug_tensor", "mlggd_comm_unique_id", "mlggd_comm_init", "mlggd_last_train_ms",
     "mlggd_profile_select", "mlggd_profile_stride", "mlggd_profile_read", "mlggd_kernel_work",
     "mlggd_debug_stamp_select", "mlggd_debug_stamp_read",
+    "mlggd_load_frames", "mlggd_train_frames", "mlggd_cv_all_frames", "mlggd_forward_frames",
+    "mlggd_alloc_pinned", "mlggd_free_pinned",
 ]
 
 _lib = None
@@ -100,6 +102,13 @@ def load():
                                     C.POINTER(C.c_double)]
     L.mlggd_debug_stamp_select.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     L.mlggd_debug_stamp_read.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.c_int, C.POINTER(C.c_int)]
+    _ip = C.POINTER(C.c_int32)
+    L.mlggd_load_frames.argtypes = [C.c_void_p, C.c_int, C.c_int, _fp, _fp, C.c_int, _ip, C.c_int]
+    L.mlggd_train_frames.argtypes = [C.c_void_p, C.c_int, C.c_int, _fp, _fp, C.c_int, _ip, C.c_int, C.POINTER(C.c_int)]
+    L.mlggd_cv_all_frames.argtypes = [C.c_void_p, C.c_int, C.c_int, _fp, _fp, C.c_int, _ip, C.c_int, _fp, _fp, _fp]
+    L.mlggd_forward_frames.argtypes = [C.c_void_p, C.c_int, C.c_int, _fp, C.c_int, _ip, _fp]
+    L.mlggd_alloc_pinned.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
+    L.mlggd_free_pinned.argtypes = [C.c_void_p]
     _lib = L
     return L
 
@@ -223,6 +232,45 @@ class BPGpu:
         trained = C.c_int(0)
         _check(load().mlggd_train_resident(self._h, int(first_frame), int(n_frames), C.byref(trained)))
         return trained.value
+
+    # -- frame-stream chunks (input pipeline on the device)
+    def _frames_args(self, feat, targ, first_frame, fea_context):
+        feat = _f32(feat)
+        first = np.ascontiguousarray(first_frame, dtype=np.int32)
+        if feat.ndim != 2 or feat.shape[1] * fea_context != self.K0:
+            raise ValueError("feat must be [n_frames][%d/fea_context]" % self.K0)
+        if targ is not None:
+            targ = _f32(targ, (feat.shape[0], self.D))
+        return feat, targ, first
+
+    def load_frames(self, feat, targ, first_frame, fea_context, targ_offset):
+        feat, targ, first = self._frames_args(feat, targ, first_frame, fea_context)
+        _check(load().mlggd_load_frames(self._h, feat.shape[0], int(fea_context), _p(feat),
+                                        _p(targ) if targ is not None else None, first.size,
+                                        first.ctypes.data_as(C.POINTER(C.c_int32)), int(targ_offset)))
+
+    def train_frames(self, feat, targ, first_frame, fea_context, targ_offset):
+        feat, targ, first = self._frames_args(feat, targ, first_frame, fea_context)
+        trained = C.c_int(0)
+        _check(load().mlggd_train_frames(self._h, feat.shape[0], int(fea_context), _p(feat), _p(targ), first.size,
+                                         first.ctypes.data_as(C.POINTER(C.c_int32)), int(targ_offset),
+                                         C.byref(trained)))
+        return trained.value
+
+    def cv_all_frames(self, feat, targ, first_frame, fea_context, targ_offset):
+        feat, targ, first = self._frames_args(feat, targ, first_frame, fea_context)
+        a, b, c = C.c_float(0), C.c_float(0), C.c_float(0)
+        _check(load().mlggd_cv_all_frames(self._h, feat.shape[0], int(fea_context), _p(feat), _p(targ), first.size,
+                                          first.ctypes.data_as(C.POINTER(C.c_int32)), int(targ_offset), C.byref(a),
+                                          C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def forward_frames(self, feat, first_frame, fea_context):
+        feat, _, first = self._frames_args(feat, None, first_frame, fea_context)
+        out = np.empty((first.size, self.D), np.float32)
+        _check(load().mlggd_forward_frames(self._h, feat.shape[0], int(fea_context), _p(feat), first.size,
+                                           first.ctypes.data_as(C.POINTER(C.c_int32)), _p(out)))
+        return out
 
     def sync(self):
         _check(load().mlggd_sync(self._h))

@@ -13,6 +13,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -122,6 +123,12 @@ struct mlggd_engine {
     float *chunk_in = nullptr, *chunk_targ = nullptr, *chunk_out = nullptr;
     size_t chunk_cap = 0, out_cap = 0;
     int chunk_frames = 0;
+    // indexed chunk: raw frame streams + first frame of every sample row
+    float *raw_feat = nullptr, *raw_targ = nullptr, *in_bunch = nullptr;
+    int *first_frame = nullptr;
+    size_t raw_cap = 0, first_cap = 0;
+    bool indexed = false;
+    int fdim = 0, toff = 0, raw_frames = 0;
     unsigned step_counter = 0;
     // launch-plan knobs (defaults chosen from measurements; env overrides for A/B runs)
     int fwd_nw = 8, dx_nw = 8, dw_tile = 1, dw_persist = 1, dwp_per_cu = 2;  // dw_tile 0 = auto
@@ -277,11 +284,33 @@ static DwpArgs dwp_args(mlggd_engine *e, int l, const float *in_rows, const floa
     return a;
 }
 
-static int run_transpose(mlggd_engine *e, const float *in, int frames) {
+// one minibatch of the resident chunk: expanded rows, or raw streams + per-row first frame
+struct Bunch {
+    const float *in;    // expanded: first row of the bunch; indexed: the raw feature stream
+    const float *targ;  // expanded: first target row;       indexed: the raw target stream
+    const int *first;   // indexed: first frame of each sample row of this bunch, else nullptr
+};
+static Bunch bunch_at(mlggd_engine *e, int sample) {
+    Bunch b;
+    if (e->indexed) {
+        b.in = e->raw_feat;
+        b.targ = e->raw_targ;
+        b.first = e->first_frame + sample;
+    } else {
+        b.in = e->chunk_in + (size_t)sample * e->K0;
+        b.targ = e->chunk_targ + (size_t)sample * e->D;
+        b.first = nullptr;
+    }
+    return b;
+}
+// row-major [frames][K0] view of the bunch for the layer-1 dW operand / dropout
+static const float *bunch_rows(mlggd_engine *e, const Bunch &b) { return b.first ? e->in_bunch : b.in; }
+
+static int run_transpose(mlggd_engine *e, const Bunch &bn, int frames) {
     ProfScope ps(e, KC_TRANSPOSE, 0);
     const int b_tiles = e->Bp / 32, k_tiles = e->lsp[0] / 32;
-    hipLaunchKernelGGL(k_transpose_in, dim3(k_tiles * b_tiles), dim3(256), 0, e->stream, in, e->K0, frames, e->K0,
-                       e->Yt[0], e->Bp, b_tiles);
+    hipLaunchKernelGGL(k_transpose_in, dim3(k_tiles * b_tiles), dim3(256), 0, e->stream, bn.in, e->K0, frames, e->K0,
+                       e->Yt[0], e->Bp, b_tiles, bn.first, e->fdim, bn.first ? e->in_bunch : (float *)nullptr);
     return launch_check("k_transpose_in");
 }
 
@@ -297,8 +326,9 @@ static int run_dropout(mlggd_engine *e, int layer, const float *chunk_rows) {
     return launch_check("k_dropout");
 }
 
-static int run_forward(mlggd_engine *e, const float *in_rows, int frames, bool training) {
-    CHK(run_transpose(e, in_rows, frames));
+static int run_forward(mlggd_engine *e, const Bunch &bn, int frames, bool training) {
+    CHK(run_transpose(e, bn, frames));
+    const float *in_rows = bunch_rows(e, bn);
     const int b_tiles = e->Bp / 32;
     const bool drop = training && e->cfg.dropoutflag == 1;
     const bool cvscale = !training && e->cfg.dropoutflag == 1;
@@ -407,7 +437,9 @@ static BiasJobs make_bias_jobs(mlggd_engine *e) {
 
 // One SGD step on `frames` (= bunchsize) resident frames: BP_GPU::train_bunch_single,
 // BP_GPU.cu:308-440.
-static int run_step(mlggd_engine *e, const float *in_rows, const float *targ_rows) {
+static int run_step(mlggd_engine *e, const Bunch &bn) {
+    const float *in_rows = bunch_rows(e, bn);
+    const float *targ_rows = bn.targ;
     const int L = e->L, B = e->B, Bp = e->Bp, b_tiles = Bp / 32;
     const bool dp = e->comm != nullptr;  // a 1-rank communicator still takes the exchange path (tests)
     const int n_global = B * e->world;
@@ -415,14 +447,14 @@ static int run_step(mlggd_engine *e, const float *in_rows, const float *targ_row
     const float inv_n = 1.0f / n_global;  // DevVecMulNum(..., 1.0f/n_frames, ...), BP_GPU.cu:409,423
     const int ML = e->cfg.MLflag;
 
-    CHK(run_forward(e, in_rows, B, true));
+    CHK(run_forward(e, bn, B, true));
     {
         ProfScope ps(e, KC_LOSS, 0);
         const size_t lds = (size_t)(32 * (Bp + 1) + 32) * sizeof(float);
         {
             hipLaunchKernelGGL(k_loss_err, dim3((e->Dp / 32) * b_tiles), dim3(256), 0, e->stream, e->slab, e->S_out,
                                e->bias[L - 1], targ_rows, B, e->D, e->Dp, Bp, e->cfg.shapefactor, ML == 1 ? 1 : 0,
-                               e->outT, e->eT, e->pT, b_tiles);
+                               e->outT, e->eT, e->pT, b_tiles, bn.first, e->toff);
             CHK(launch_check("k_loss_err"));
             const float *colsum_in = nullptr;
             if (dp && ML == 1) {
@@ -570,6 +602,7 @@ int mlggd_create(const mlggd_config *cfg, const float *const *weights, const flo
 
     const int L = e->L, Bp = e->Bp;
     CHK(dev_alloc(e, &e->Yt[0], (size_t)e->lsp[0] * Bp));
+    CHK(dev_alloc(e, &e->in_bunch, (size_t)(Bp + 1) * e->lsp[0]));
     for (int l = 1; l < L; l++) {
         const size_t wsz = (size_t)e->lsp[l - 1] * e->lsp[l];
         CHK(dev_alloc(e, &e->W[l], wsz));
@@ -618,6 +651,9 @@ int mlggd_destroy(mlggd_handle e) {
     if (e->chunk_in) hipFree(e->chunk_in);
     if (e->chunk_targ) hipFree(e->chunk_targ);
     if (e->chunk_out) hipFree(e->chunk_out);
+    if (e->raw_feat) hipFree(e->raw_feat);
+    if (e->raw_targ) hipFree(e->raw_targ);
+    if (e->first_frame) hipFree(e->first_frame);
     for (hipEvent_t ev : e->prof_ev) hipEventDestroy(ev);
     for (int l = 0; l < MLGGD_MAXLAYER; l++) {
         if (e->ev_grad[l]) hipEventDestroy(e->ev_grad[l]);
@@ -719,6 +755,80 @@ int mlggd_load_chunk(mlggd_handle e, int n_frames, const float *in, const float 
     }
     HIPCHK(hipStreamSynchronize(e->stream));
     e->chunk_frames = n_frames;
+    e->indexed = false;
+    return MLGGD_OK;
+}
+
+// the chunk as raw frame streams + the first frame of every sample row.
+int mlggd_load_frames(mlggd_handle e, int n_frames, int fea_context, const float *feat, const float *targ,
+                      int n_samples, const int32_t *first_frame, int targ_offset) {
+    if (!e) return fail(MLGGD_ERR_ARG, "NULL handle");
+    if (fea_context < 1 || e->K0 % fea_context != 0)
+        return fail(MLGGD_ERR_ARG, "fea_context %d does not divide layersizes[0] = %d", fea_context, e->K0);
+    const int fdim = e->K0 / fea_context;
+    if (n_frames < 0 || n_samples < 0) return fail(MLGGD_ERR_ARG, "negative size");
+    CHK(check_frames(e, n_samples));
+    if (n_samples > 0 && (!feat || !first_frame)) return fail(MLGGD_ERR_ARG, "feat/first_frame is NULL");
+    if (targ_offset < 0 || targ_offset >= fea_context)
+        return fail(MLGGD_ERR_ARG, "targ_offset %d not in [0, fea_context)", targ_offset);
+    for (int s = 0; s < n_samples; s++)
+        if (first_frame[s] < 0 || first_frame[s] + fea_context > n_frames)
+            return fail(MLGGD_ERR_ARG, "sample %d: window [%d,%d) outside the %d uploaded frames", s, first_frame[s],
+                        first_frame[s] + fea_context, n_frames);
+    HIPCHK(hipSetDevice(e->device));
+    const size_t need = (size_t)n_frames + fea_context + 8;
+    if (need > e->raw_cap) {
+        if (e->raw_feat) hipFree(e->raw_feat);
+        if (e->raw_targ) hipFree(e->raw_targ);
+        e->raw_feat = e->raw_targ = nullptr;
+        e->raw_cap = 0;
+        HIPCHK(hipMalloc((void **)&e->raw_feat, need * fdim * sizeof(float)));
+        HIPCHK(hipMalloc((void **)&e->raw_targ, need * e->D * sizeof(float)));
+        HIPCHK(hipMemsetAsync(e->raw_feat, 0, need * fdim * sizeof(float), e->stream));
+        HIPCHK(hipMemsetAsync(e->raw_targ, 0, need * e->D * sizeof(float), e->stream));
+        e->raw_cap = need;
+    }
+    const size_t need_s = (size_t)n_samples + e->Bp + 32;
+    if (need_s > e->first_cap) {
+        if (e->first_frame) hipFree(e->first_frame);
+        e->first_frame = nullptr;
+        e->first_cap = 0;
+        HIPCHK(hipMalloc((void **)&e->first_frame, need_s * sizeof(int)));
+        HIPCHK(hipMemsetAsync(e->first_frame, 0, need_s * sizeof(int), e->stream));
+        e->first_cap = need_s;
+    }
+    if (n_frames > 0) {
+        HIPCHK(hipMemcpyAsync(e->raw_feat, feat, (size_t)n_frames * fdim * 4, hipMemcpyHostToDevice, e->stream));
+        if (targ)
+            HIPCHK(hipMemcpyAsync(e->raw_targ, targ, (size_t)n_frames * e->D * 4, hipMemcpyHostToDevice, e->stream));
+    }
+    if (n_samples > 0)
+        HIPCHK(hipMemcpyAsync(e->first_frame, first_frame, (size_t)n_samples * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->chunk_frames = n_samples;
+    e->raw_frames = n_frames;
+    e->indexed = true;
+    e->fdim = fdim;
+    e->toff = targ_offset;
+    return MLGGD_OK;
+}
+
+int mlggd_train_frames(mlggd_handle e, int n_frames, int fea_context, const float *feat, const float *targ,
+                       int n_samples, const int32_t *first_frame, int targ_offset, int *bunches_trained) {
+    if (n_samples > 0 && !targ) return fail(MLGGD_ERR_ARG, "targ is NULL");
+    CHK(mlggd_load_frames(e, n_frames, fea_context, feat, targ, n_samples, first_frame, targ_offset));
+    CHK(mlggd_train_resident(e, 0, n_samples, bunches_trained));
+    return mlggd_sync(e);
+}
+
+// Pinned host memory for the caller's chunk buffers (faster, truly asynchronous H2D).
+int mlggd_alloc_pinned(size_t bytes, void **out) {
+    if (!out) return fail(MLGGD_ERR_ARG, "out is NULL");
+    HIPCHK(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    return MLGGD_OK;
+}
+int mlggd_free_pinned(void *p) {
+    if (p) HIPCHK(hipHostFree(p));
     return MLGGD_OK;
 }
 
@@ -732,9 +842,7 @@ int mlggd_train_resident(mlggd_handle e, int first_frame, int n_frames, int *bun
     HIPCHK(hipEventRecord(e->ev_t0, e->stream));
     // bunch loop of BP_GPU::train, BP_GPU.cu:170-184: full bunches only
     for (int i = 0; i + e->B <= n_frames; i += e->B) {
-        const float *in_rows = e->chunk_in + (size_t)(first_frame + i) * e->K0;
-        const float *targ_rows = e->chunk_targ + (size_t)(first_frame + i) * e->D;
-        CHK(run_step(e, in_rows, targ_rows));
+        CHK(run_step(e, bunch_at(e, first_frame + i)));
         trained++;
     }
     HIPCHK(hipEventRecord(e->ev_t1, e->stream));
@@ -784,7 +892,7 @@ static int forward_resident(mlggd_engine *e, int n_frames) {
     // bunch loop of CrossValid*, BP_GPU.cu:202-216: INCLUDES the trailing partial bunch
     for (int i = 0; i < n_frames; i += e->B) {
         const int fb = (e->B > n_frames - i) ? (n_frames - i) : e->B;
-        CHK(run_forward(e, e->chunk_in + (size_t)i * e->K0, fb, false));
+        CHK(run_forward(e, bunch_at(e, i), fb, false));
         hipLaunchKernelGGL(k_out_rowmajor, dim3((e->Dp / 32) * b_tiles), dim3(256), 0, e->stream, e->slab, e->S_out,
                            e->bias[e->L - 1], fb, e->D, e->Dp, e->Bp, e->chunk_out + (size_t)i * e->D, b_tiles);
         CHK(launch_check("k_out_rowmajor"));
@@ -832,11 +940,10 @@ float mlggd_gamma(float x) {
 }
 
 // Host accumulation exactly as CrossValid / CrossValiddB / CrossValid2 do it
-// (BP_GPU.cu:207-213, 240-250, 271-301): fp32 scalars, frame-major order.
-static int cv_metrics(mlggd_engine *e, int n_frames, const float *in, const float *targ, float *sqerr, float *abserr,
-                      float *loglik) {
-    if (n_frames > 0 && (!in || !targ)) return fail(MLGGD_ERR_ARG, "in/targ is NULL");
-    CHK(mlggd_load_chunk(e, n_frames, in, nullptr));
+// (BP_GPU.cu:207-213, 240-250, 271-301): fp32 scalars, frame-major order.  The chunk must be
+// resident (expanded or indexed); target of sample i is trow(i).
+static int cv_accumulate(mlggd_engine *e, int n_frames, const std::function<const float *(int)> &trow, float *sqerr,
+                         float *abserr, float *loglik) {
     const int D = e->D;
     std::vector<float> out((size_t)n_frames * D);
     if (n_frames > 0) {
@@ -847,15 +954,20 @@ static int cv_metrics(mlggd_engine *e, int n_frames, const float *in, const floa
     if (loglik)
         HIPCHK(hipMemcpyAsync(scalefac.data(), e->scalefactor, (size_t)D * 4, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
-    const size_t total = (size_t)n_frames * D;
     if (sqerr) {
         float s = 0.0f;
-        for (size_t i = 0; i < total; i++) s = s + (out[i] - targ[i]) * (out[i] - targ[i]);
+        for (int i = 0; i < n_frames; i++) {
+            const float *t = trow(i), *o = &out[(size_t)i * D];
+            for (int d = 0; d < D; d++) s = s + (o[d] - t[d]) * (o[d] - t[d]);
+        }
         *sqerr = s;
     }
     if (abserr) {
         float s = 0.0f;
-        for (size_t i = 0; i < total; i++) s = s + fabsf(out[i] - targ[i]);
+        for (int i = 0; i < n_frames; i++) {
+            const float *t = trow(i), *o = &out[(size_t)i * D];
+            for (int d = 0; d < D; d++) s = s + fabsf(o[d] - t[d]);
+        }
         *abserr = s / D;
     }
     if (loglik) {
@@ -864,13 +976,24 @@ static int cv_metrics(mlggd_engine *e, int n_frames, const float *in, const floa
         density1 = n_frames * D * logf(beta / (2 * mlggd_gamma((float)(1.0 / beta))));
         for (int u = 0; u < D; u++) density2 += logf(scalefac[u]);
         density2 = density2 * n_frames;
-        for (size_t i = 0; i < total; i++) {
-            const float err = targ[i] - out[i];
-            density3 += powf(fabsf(err) / scalefac[i % D], beta);
+        for (int i = 0; i < n_frames; i++) {
+            const float *t = trow(i), *o = &out[(size_t)i * D];
+            for (int d = 0; d < D; d++) {
+                const float err = t[d] - o[d];
+                density3 += powf(fabsf(err) / scalefac[d], beta);
+            }
         }
         *loglik = density1 - density2 - density3;
     }
     return MLGGD_OK;
+}
+
+static int cv_metrics(mlggd_engine *e, int n_frames, const float *in, const float *targ, float *sqerr, float *abserr,
+                      float *loglik) {
+    if (n_frames > 0 && (!in || !targ)) return fail(MLGGD_ERR_ARG, "in/targ is NULL");
+    CHK(mlggd_load_chunk(e, n_frames, in, nullptr));
+    const int D = e->D;
+    return cv_accumulate(e, n_frames, [&](int i) { return targ + (size_t)i * D; }, sqerr, abserr, loglik);
 }
 
 int mlggd_cv_sqerr(mlggd_handle e, int n, const float *in, const float *targ, float *out) {
@@ -889,6 +1012,30 @@ int mlggd_cv_all(mlggd_handle e, int n, const float *in, const float *targ, floa
                  float *loglik) {
     if (!e) return fail(MLGGD_ERR_ARG, "NULL handle");
     return cv_metrics(e, n, in, targ, sqerr, abserr, (e->cfg.MLflag == 1) ? loglik : nullptr);
+}
+
+int mlggd_cv_all_frames(mlggd_handle e, int n_frames, int fea_context, const float *feat, const float *targ,
+                        int n_samples, const int32_t *first_frame, int targ_offset, float *sqerr, float *abserr,
+                        float *loglik) {
+    if (!e) return fail(MLGGD_ERR_ARG, "NULL handle");
+    if (n_samples > 0 && !targ) return fail(MLGGD_ERR_ARG, "targ is NULL");
+    CHK(mlggd_load_frames(e, n_frames, fea_context, feat, nullptr, n_samples, first_frame, targ_offset));
+    const int D = e->D;
+    return cv_accumulate(
+        e, n_samples, [&](int i) { return targ + (size_t)(first_frame[i] + targ_offset) * D; }, sqerr, abserr,
+        (e->cfg.MLflag == 1) ? loglik : nullptr);
+}
+
+int mlggd_forward_frames(mlggd_handle e, int n_frames, int fea_context, const float *feat, int n_samples,
+                         const int32_t *first_frame, float *out) {
+    if (!e) return fail(MLGGD_ERR_ARG, "NULL handle");
+    if (n_samples > 0 && !out) return fail(MLGGD_ERR_ARG, "out is NULL");
+    CHK(mlggd_load_frames(e, n_frames, fea_context, feat, nullptr, n_samples, first_frame, 0));
+    if (n_samples == 0) return MLGGD_OK;
+    CHK(forward_resident(e, n_samples));
+    HIPCHK(hipMemcpyAsync(out, e->chunk_out, (size_t)n_samples * e->D * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return MLGGD_OK;
 }
 
 int mlggd_debug_tensor(mlggd_handle e, const char *name, int layer, float *dst, size_t count) {

@@ -887,11 +887,19 @@ __global__ __launch_bounds__(256) void k_bias_apply(BiasJobs jobs, float nf, flo
 }
 
 // ---------------------------------------------------------------------------------------
-// Input staging: in[b][k] (row stride ld, the caller's chunk layout) -> inT[k][b] padded
-// with zeros (k >= K or b >= B).  32x32 tiles through LDS; both sides coalesced.
+// Input staging: row b of the minibatch -> inT[k][b], padded with zeros (k >= K or b >= B).
+// 32x32 tiles through LDS; both sides coalesced.  Two sources (Interface::Readchunk,
+// Interface.cc:778-785, builds row b as the fea_context consecutive frames of one window):
+//   first == nullptr : the caller's expanded chunk, row b at in + b*ld           (BP_GPU::train)
+//   first != nullptr : the raw frame stream; row b is the contiguous slice that starts at frame
+//                      first[b], i.e. in + first[b]*fdim  (the window IS consecutive frames, so
+//                      nothing has to be expanded on the host).  The gathered rows are also
+//                      written row-major to rows_out[b][K] for the layer-1 dW operand.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_transpose_in(const float *__restrict__ in, int ld, int B, int K,
-                                                      float *__restrict__ inT, int Bp, int b_tiles) {
+                                                      float *__restrict__ inT, int Bp, int b_tiles,
+                                                      const int *__restrict__ first, int fdim,
+                                                      float *__restrict__ rows_out) {
     __shared__ float t[32][33];
     const int kt = blockIdx.x / b_tiles, bt = blockIdx.x % b_tiles;
     const int k0 = kt * 32, b0 = bt * 32;
@@ -899,7 +907,13 @@ __global__ __launch_bounds__(256) void k_transpose_in(const float *__restrict__ 
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const int b = b0 + ty + 8 * q, k = k0 + tx;
-        t[ty + 8 * q][tx] = (b < B && k < K) ? in[(size_t)b * ld + k] : 0.0f;
+        float v = 0.0f;
+        if (b < B && k < K) {
+            const size_t base = first ? (size_t)first[b] * fdim : (size_t)b * ld;
+            v = in[base + k];
+            if (rows_out) rows_out[(size_t)b * K + k] = v;
+        }
+        t[ty + 8 * q][tx] = v;
     }
     __syncthreads();
 #pragma unroll
@@ -933,7 +947,10 @@ __device__ __forceinline__ float slab_sum(const float *__restrict__ slab, size_t
 __global__ __launch_bounds__(256) void k_loss_err(const float *__restrict__ slab, int S, const float *__restrict__ bias,
                                                   const float *__restrict__ targ, int B, int D, int Dp, int Bp,
                                                   float beta, int want_pow, float *__restrict__ outT,
-                                                  float *__restrict__ eT, float *__restrict__ pT, int b_tiles) {
+                                                  float *__restrict__ eT, float *__restrict__ pT, int b_tiles,
+                                                  const int *__restrict__ first, int toff) {
+    // first != nullptr: targ is the raw target frame stream and sample b's target is frame
+    // first[b] + toff of it (Interface.cc:822-825); otherwise row b of the caller's [B][D] matrix
     __shared__ float tt[32][33];
     const int dt = blockIdx.x / b_tiles, bt = blockIdx.x % b_tiles;
     const int d0 = dt * 32, b0 = bt * 32;
@@ -941,7 +958,7 @@ __global__ __launch_bounds__(256) void k_loss_err(const float *__restrict__ slab
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const int b = b0 + ty + 8 * q, d = d0 + tx;
-        tt[ty + 8 * q][tx] = (b < B && d < D) ? targ[(size_t)b * D + d] : 0.0f;
+        tt[ty + 8 * q][tx] = (b < B && d < D) ? targ[(size_t)(first ? first[b] + toff : b) * D + d] : 0.0f;
     }
     __syncthreads();
     const size_t slab_stride = (size_t)Dp * Bp;

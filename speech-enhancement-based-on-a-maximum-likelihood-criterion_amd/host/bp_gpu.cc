@@ -71,6 +71,20 @@ void BP_GPU::CrossValidAll(int n, const float *in, const float *targ, float *sqe
 void BP_GPU::cv_bunch_single(int n, const float *in, float *out) {
     check(mlggd_forward(h_, n, in, out), "mlggd_forward");
 }
+void BP_GPU::train_frames(int n_frames, int fea_context, const float *feat, const float *targ, int n_samples,
+                          const int *first_frame, int targ_offset) {
+    int trained = 0;
+    check(mlggd_train_frames(h_, n_frames, fea_context, feat, targ, n_samples, first_frame, targ_offset, &trained),
+          "mlggd_train_frames");
+    const int rest = n_samples - trained * bunchsize;
+    if (rest > 0) printf("this bunch has only %d samples and is ignored.\n", rest);  // BP_GPU.cu:179
+}
+void BP_GPU::CrossValidAll_frames(int n_frames, int fea_context, const float *feat, const float *targ, int n_samples,
+                                  const int *first_frame, int targ_offset, float *sqerr, float *abserr, float *loglik) {
+    check(mlggd_cv_all_frames(h_, n_frames, fea_context, feat, targ, n_samples, first_frame, targ_offset, sqerr, abserr,
+                              loglik),
+          "mlggd_cv_all_frames");
+}
 void BP_GPU::returnWeights(float **weights, float **bias) {
     check(mlggd_get_weights(h_, weights, bias), "mlggd_get_weights");
 }

@@ -19,6 +19,11 @@ class BP_GPU {
     // one forward pass for all three metrics (same accumulation order as the three above)
     void CrossValidAll(int n_frames, const float *in, const float *targ, float *sqerr, float *abserr, float *loglik);
     void cv_bunch_single(int n_frames, const float *in, float *out);
+    // frame-stream chunks (not in the reference): rows gathered on the device, see mlggd_load_frames
+    void train_frames(int n_frames, int fea_context, const float *feat, const float *targ, int n_samples,
+                      const int *first_frame, int targ_offset);
+    void CrossValidAll_frames(int n_frames, int fea_context, const float *feat, const float *targ, int n_samples,
+                              const int *first_frame, int targ_offset, float *sqerr, float *abserr, float *loglik);
     void returnWeights(float **weights, float **bias);
     float Gamma(float x) { return mlggd_gamma(x); }
     // data parallel (not in the reference): join an RCCL communicator of `world` ranks

@@ -7,6 +7,10 @@
 // read, in read order) -> prefetch thread reads chunk i+1 while the GPU trains on chunk i ->
 // write weights -> cross-validate -> three log lines.
 //
+// Input pipeline (new): by default chunks travel as raw normalised frames plus the
+// first frame of every (shuffled) sample row and are gathered on the GPU; MLGGD_EXPANDED=1 selects
+// the reference's host-side context expansion (Interface::Readchunk) instead -- same results.
+//
 // Data parallel (new): when WORLD_SIZE > 1 (torchrun-style env: RANK,
 // LOCAL_RANK, WORLD_SIZE; MLGGD_ID_FILE names a file on a shared filesystem used to hand the
 // RCCL unique id from rank 0 to the others) every rank reads the same chunks with the same
@@ -52,19 +56,28 @@ struct Slot {
     }
 };
 
-void swap_buffers(WorkPara *p) {  // BPtrain.cc:25-32
-    std::swap(p->indata[0], p->indata[1]);
-    std::swap(p->targ[0], p->targ[1]);
+void swap_buffers(Interface *io, bool frames) {  // BPtrain.cc:25-32
+    WorkPara *p = io->para;
+    if (frames) {
+        std::swap(p->frames_in[0], p->frames_in[1]);
+        std::swap(p->frames_targ[0], p->frames_targ[1]);
+        std::swap(p->first_frame[0], p->first_frame[1]);
+        std::swap(p->chunk_frames[0], p->chunk_frames[1]);
+        io->frames_swapped();
+    } else {
+        std::swap(p->indata[0], p->indata[1]);
+        std::swap(p->targ[0], p->targ[1]);
+    }
 }
 
 // threadFetch, BPtrain.cc:15-54
-void fetch_loop(Interface *io, Slot *slot, std::string *error) {
+void fetch_loop(Interface *io, Slot *slot, std::string *error, bool frames) {
     try {
         for (unsigned i = 0; i < io->total_chunks; i++) {
-            const int n = io->Readchunk(io->chunk_index[i]);  // into indata[0]/targ[0]
+            const int n = frames ? io->Readchunk_frames(io->chunk_index[i]) : io->Readchunk(io->chunk_index[i]);
             if (i > 0) slot->wait(false);                      // trainer done with indata[1]
             io->cur_chunk_samples = n;
-            swap_buffers(io->para);
+            swap_buffers(io, frames);
             slot->set(true);
         }
     } catch (const std::exception &e) {
@@ -134,7 +147,8 @@ int main(int argc, char *argv[]) {
 
         Slot slot;
         std::string fetch_error;
-        std::thread fetch(fetch_loop, io, &slot, &fetch_error);
+        const bool frames = env_int("MLGGD_EXPANDED", 0) == 0;
+        std::thread fetch(fetch_loop, io, &slot, &fetch_error, frames);
         const int K0 = p->layersizes[0], D = p->layersizes[io->numlayers - 1], B = p->bunchsize;
         std::vector<float> loc_in, loc_targ;
         for (unsigned i = 0; i < io->total_chunks; i++) {
@@ -142,11 +156,26 @@ int main(int argc, char *argv[]) {
             if (io->cur_chunk_samples < 0) break;
             io->logf("Starting chunk %d of %d containing %d samples.\n", i + 1, io->total_chunks, io->cur_chunk_samples);
             if (io->fp_log) fflush(io->fp_log);
-            if (world == 1) {
-                net->train(io->cur_chunk_samples, p->indata[1], p->targ[1]);
+            const int ns = io->cur_chunk_samples;
+            if (frames) {
+                const int *first = p->first_frame[1];
+                std::vector<int> loc_first;
+                int nloc = ns;
+                if (world > 1) {  // this rank's rows of every complete global minibatch
+                    const int gb = B * world, nglob = ns / gb;
+                    loc_first.resize((size_t)nglob * B);
+                    for (int g = 0; g < nglob; g++)
+                        memcpy(&loc_first[(size_t)g * B], first + (size_t)g * gb + (size_t)rank * B, (size_t)B * sizeof(int));
+                    first = loc_first.data();
+                    nloc = nglob * B;
+                }
+                net->train_frames(p->chunk_frames[1], p->fea_context, p->frames_in[1], p->frames_targ[1], nloc, first,
+                                  p->targ_offset);
+            } else if (world == 1) {
+                net->train(ns, p->indata[1], p->targ[1]);
             } else {
                 // this rank's rows of every complete global minibatch, compacted
-                const int gb = B * world, nglob = io->cur_chunk_samples / gb;
+                const int gb = B * world, nglob = ns / gb;
                 loc_in.resize((size_t)nglob * B * K0);
                 loc_targ.resize((size_t)nglob * B * D);
                 for (int g = 0; g < nglob; g++) {
@@ -175,10 +204,17 @@ int main(int argc, char *argv[]) {
             io->get_chunk_info_cv(p->cv_sent_range);
             float squared_err = 0.0f, dB_squared_err = 0.0f, likelihood = 0.0f;
             for (unsigned i = 0; i < io->cv_total_chunks; i++) {
-                const int n = io->Readchunk_cv((int)i);
-                printf("cur_chunk_samples=%d\n", n);
                 float sq = 0, ab = 0, ll = 0;
-                net->CrossValidAll(n, p->indata[0], p->targ[0], &sq, &ab, &ll);
+                int n;
+                if (frames) {
+                    n = io->Readchunk_frames_cv((int)i);
+                    net->CrossValidAll_frames(p->chunk_frames[0], p->fea_context, p->frames_in[0], p->frames_targ[0], n,
+                                              p->first_frame[0], p->targ_offset, &sq, &ab, &ll);
+                } else {
+                    n = io->Readchunk_cv((int)i);
+                    net->CrossValidAll(n, p->indata[0], p->targ[0], &sq, &ab, &ll);
+                }
+                printf("cur_chunk_samples=%d\n", n);
                 squared_err += sq;
                 dB_squared_err += ab;
                 if (p->MLflag == 1) likelihood += ll;

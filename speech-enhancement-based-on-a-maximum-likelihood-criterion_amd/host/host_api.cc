@@ -78,6 +78,25 @@ int mlggd_host_read_chunk(void *h, int index, int cv, float *in, float *targ) {
     }
 }
 
+// frame-stream form of the same chunk: raw normalised frames + first frame per row.
+// Returns samples (or -1); *nframes receives the number of frames copied.
+int mlggd_host_read_chunk_frames(void *h, int index, int cv, float *feat, float *targ, int *first, int *nframes) {
+    Interface *io = (Interface *)h;
+    try {
+        const int n = cv ? io->Readchunk_frames_cv(index) : io->Readchunk_frames(index);
+        const WorkPara *p = io->para;
+        const int fr = p->chunk_frames[0];
+        memcpy(feat, p->frames_in[0], (size_t)fr * p->fea_dim * sizeof(float));
+        memcpy(targ, p->frames_targ[0], (size_t)fr * p->layersizes[io->numlayers - 1] * sizeof(float));
+        memcpy(first, p->first_frame[0], (size_t)n * sizeof(int));
+        *nframes = fr;
+        return n;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
 void mlggd_host_shuffle(void *h, int *vec, int len) { ((Interface *)h)->GetRandIndex(vec, len); }
 
 int mlggd_host_weights(void *h, int layer, float *w, float *b) {

@@ -248,13 +248,21 @@ void Interface::Initial(int argc, char **argv, bool open_output) {
     load_init_weights();
     if (p.fea_dim * p.fea_context != p.layersizes[0])  // Interface.cc:471-475
         throw IoError("feadim times context must be equal to layersizes[0]");
-    for (int i = 0; i < 2; i++) {  // Interface.cc:476-480
+    // Interface.cc:476-480 allocates two [traincache][layersizes[0]] matrices up front; here they are
+    // allocated on first use of the expanding reader (the frame-stream reader does not need them)
+    if (fp_log) fflush(fp_log);
+}
+
+void Interface::want_expanded_buffers() {
+    if (expanded_ready_) return;
+    WorkPara &p = *para;
+    for (int i = 0; i < 2; i++) {
         buf_in_[i].assign((size_t)p.layersizes[0] * p.traincache, 0.f);
         buf_targ_[i].assign((size_t)p.layersizes[numlayers - 1] * p.traincache, 0.f);
         p.indata[i] = buf_in_[i].data();
         p.targ[i] = buf_targ_[i].data();
     }
-    if (fp_log) fflush(fp_log);
+    expanded_ready_ = true;
 }
 
 // Interface::Writeweights, Interface.cc:484-516
@@ -392,7 +400,7 @@ void Interface::GetRandIndex(int *vec, int len) {
 // (Interface.cc:763-764, 807-808), and writes sample s (a window of fea_context frames that
 // lies inside one sentence and inside the chunk) to row order[s] of indata[0], its target
 // (the frame targ_offset into the window) to row order[s] of targ[0].
-int Interface::read_chunk(const ChunkPlan &plan, int index, bool shuffle) {
+int Interface::read_chunk(const ChunkPlan &plan, int index, bool shuffle, bool expand) {
     const WorkPara &p = *para;
     const int dim = p.fea_dim, ctx = p.fea_context, K0 = p.layersizes[0], D = p.layersizes[numlayers - 1];
     const int st = plan.frame_st[index];
@@ -437,25 +445,44 @@ int Interface::read_chunk(const ChunkPlan &plan, int index, bool shuffle) {
         return sample;
     };
 
-    std::vector<float> feat, targ;
     int sent0 = 0;
-    load(fp_data, dim, feat, sent0);
-    float *in0 = p.indata[0];
-    walk(sent0, [&](int s, int f) {
-        if (s < samples)
-            memcpy(in0 + (size_t)order[s] * K0, feat.data() + (size_t)f * dim, (size_t)ctx * dim * sizeof(float));
-    });
-    load(fp_targ, D, targ, sent0);
-    float *tg0 = p.targ[0];
-    walk(sent0, [&](int s, int f) {
-        if (s < samples)
-            memcpy(tg0 + (size_t)order[s] * D, targ.data() + (size_t)(f + p.targ_offset) * D, (size_t)D * sizeof(float));
-    });
+    if (expand) {
+        want_expanded_buffers();
+        std::vector<float> feat, targ;
+        load(fp_data, dim, feat, sent0);
+        float *in0 = p.indata[0];
+        walk(sent0, [&](int s, int f) {
+            if (s < samples)
+                memcpy(in0 + (size_t)order[s] * K0, feat.data() + (size_t)f * dim, (size_t)ctx * dim * sizeof(float));
+        });
+        load(fp_targ, D, targ, sent0);
+        float *tg0 = p.targ[0];
+        walk(sent0, [&](int s, int f) {
+            if (s < samples)
+                memcpy(tg0 + (size_t)order[s] * D, targ.data() + (size_t)(f + p.targ_offset) * D, (size_t)D * sizeof(float));
+        });
+    } else {
+        // frame-stream form: keep the normalised frames, record where each row's window starts
+        const int fi = fr_fill_;
+        load(fp_data, dim, fr_in_[fi], sent0);
+        load(fp_targ, D, fr_targ_[fi], sent0);
+        fr_first_[fi].assign(samples, 0);
+        int *first = fr_first_[fi].data();
+        walk(sent0, [&](int s, int f) {
+            if (s < samples) first[order[s]] = f;
+        });
+        para->frames_in[0] = fr_in_[fi].data();
+        para->frames_targ[0] = fr_targ_[fi].data();
+        para->first_frame[0] = first;
+        para->chunk_frames[0] = frames;
+    }
     return samples;
 }
 
-int Interface::Readchunk(int index) { return read_chunk(train_plan, index, true); }
-int Interface::Readchunk_cv(int index) { return read_chunk(cv_plan, index, false); }
+int Interface::Readchunk(int index) { return read_chunk(train_plan, index, true, true); }
+int Interface::Readchunk_cv(int index) { return read_chunk(cv_plan, index, false, true); }
+int Interface::Readchunk_frames(int index) { return read_chunk(train_plan, index, true, false); }
+int Interface::Readchunk_frames_cv(int index) { return read_chunk(cv_plan, index, false, false); }
 
 // ---- pfile writer (for synthetic data; layout as parsed above and in SURVEY.md 8c)
 void write_pfile(const std::string &path, const std::vector<int> &sent_lengths, int num_features, const float *features) {

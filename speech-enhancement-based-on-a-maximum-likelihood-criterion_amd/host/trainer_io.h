@@ -35,6 +35,11 @@ struct WorkPara {
     int MLflag = 0, gpu_used = 0, init_randem_seed = 0;
     float init_randem_weight_min = -0.1f, init_randem_weight_max = 0.1f;
     float init_randem_bias_min = -0.1f, init_randem_bias_max = 0.1f;
+    // frame-stream chunk (device-side input pipeline): raw normalised frames + first frame of every row
+    float *frames_in[2] = {nullptr, nullptr};    // [chunk frames][fea_dim]
+    float *frames_targ[2] = {nullptr, nullptr};  // [chunk frames][layersizes[L-1]]
+    int *first_frame[2] = {nullptr, nullptr};    // [samples]
+    int chunk_frames[2] = {0, 0};
     float *indata[2] = {nullptr, nullptr};  // double buffer, [traincache][layersizes[0]]
     float *targ[2] = {nullptr, nullptr};    //                [traincache][layersizes[L-1]]
     float *weights[kMaxLayer] = {nullptr};  // index 1..L-1, row-major [in][out]
@@ -60,6 +65,15 @@ class Interface {
     void get_chunk_info_cv(const std::string &range);
     int Readchunk(int index);     // fills para->indata[0] / targ[0]; returns samples
     int Readchunk_cv(int index);
+    // The same chunk WITHOUT host-side context expansion: fills para->frames_in[0] / frames_targ[0]
+    // (normalised frames of the chunk) and para->first_frame[0][row] = first frame of the sample
+    // that Readchunk would have expanded into that row (same lrand48 draw).  Returns samples.
+    int Readchunk_frames(int index);
+    int Readchunk_frames_cv(int index);
+    // expanded buffers are only allocated on demand (Readchunk/Readchunk_cv)
+    void want_expanded_buffers();
+    // call after handing slot 0 of the frame-stream buffers to the consumer (pointer swap 0<->1)
+    void frames_swapped() { fr_fill_ ^= 1; }
     void GetRandIndex(int *vec, int len);
     void logf(const char *fmt, ...);
 
@@ -82,13 +96,16 @@ class Interface {
     void load_norm();
     void load_init_weights();
     ChunkPlan plan_chunks(const std::string &range, const char *what);
-    int read_chunk(const ChunkPlan &plan, int index, bool shuffle);
+    int read_chunk(const ChunkPlan &plan, int index, bool shuffle, bool expand);
     static unsigned header_uint(const std::string &hdr, const char *key, FILE *log);
     void read_sentence_table(FILE *fp, long offset, unsigned nsent, std::vector<int> &out);
 
     FILE *fp_data = nullptr, *fp_targ = nullptr, *fp_out = nullptr;
     std::vector<float> mean_, dVar_;
-    std::vector<float> buf_in_[2], buf_targ_[2];
+    std::vector<float> buf_in_[2], buf_targ_[2], fr_in_[2], fr_targ_[2];
+    std::vector<int> fr_first_[2];
+    bool expanded_ready_ = false;
+    int fr_fill_ = 0;  // which frame-stream buffer the next Readchunk_frames fills
     std::vector<std::vector<float>> w_, b_;
 };
 

@@ -25,6 +25,8 @@ def lib():
         L.mlggd_host_norm.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int]
         L.mlggd_host_plan.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_uint)]
         L.mlggd_host_read_chunk.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.mlggd_host_read_chunk_frames.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float),
+                                                   C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.mlggd_host_shuffle.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int]
         L.mlggd_host_weights.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.mlggd_host_write_pfile.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(C.c_float)]
@@ -89,6 +91,18 @@ class HostIO:
         if n < 0:
             raise HostError(lib().mlggd_host_last_error().decode())
         return inp[:n], targ[:n]
+
+    def read_chunk_frames(self, index, dim, D, cap_frames, cap_samples, cv=False):
+        feat = np.zeros((cap_frames, dim), np.float32)
+        targ = np.zeros((cap_frames, D), np.float32)
+        first = np.zeros(cap_samples, np.int32)
+        nfr = C.c_int(0)
+        n = lib().mlggd_host_read_chunk_frames(self.h, index, int(cv), feat.ctypes.data_as(C.POINTER(C.c_float)),
+                                               targ.ctypes.data_as(C.POINTER(C.c_float)),
+                                               first.ctypes.data_as(C.POINTER(C.c_int)), C.byref(nfr))
+        if n < 0:
+            raise HostError(lib().mlggd_host_last_error().decode())
+        return feat[:nfr.value], targ[:nfr.value], first[:n]
 
     def shuffle(self, n):
         v = (C.c_int * n)(*range(n))
@@ -158,6 +172,18 @@ class Rand48:
     def lrand48(self):
         self.x = (0x5DEECE66D * self.x + 0xB) & ((1 << 48) - 1)
         return self.x >> 17
+
+    def read_chunk_frames(self, index, dim, D, cap_frames, cap_samples, cv=False):
+        feat = np.zeros((cap_frames, dim), np.float32)
+        targ = np.zeros((cap_frames, D), np.float32)
+        first = np.zeros(cap_samples, np.int32)
+        nfr = C.c_int(0)
+        n = lib().mlggd_host_read_chunk_frames(self.h, index, int(cv), feat.ctypes.data_as(C.POINTER(C.c_float)),
+                                               targ.ctypes.data_as(C.POINTER(C.c_float)),
+                                               first.ctypes.data_as(C.POINTER(C.c_int)), C.byref(nfr))
+        if n < 0:
+            raise HostError(lib().mlggd_host_last_error().decode())
+        return feat[:nfr.value], targ[:nfr.value], first[:n]
 
     def shuffle(self, n):  # Interface::GetRandIndex, Interface.cc:975-986
         v = list(range(n))

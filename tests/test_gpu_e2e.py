@@ -92,6 +92,35 @@ def test_exchange_path_on_one_rank_communicator(pkg, pyoracle, synth, ml, beta):
     eng.close()
 
 
+@pytest.mark.parametrize("ml,beta", [(0, 2.0), (1, 1.2)])
+def test_frame_stream_chunks_equal_expanded_chunks_bitwise(pkg, synth, ml, beta):
+    """rows gathered on the device from the raw frame stream == the host-expanded
+    matrix, bit for bit (weights, CV metrics, forward outputs), incl. a shuffled row order."""
+    dim, ctx, B, toff = 257, 11, 128, 5
+    ls = [dim * ctx, 512, 384, dim]
+    rng = np.random.default_rng(3)
+    nfr = 700
+    feat = rng.standard_normal((nfr, dim), dtype=np.float32)
+    targ = (0.5 * feat + 0.5 * rng.standard_normal((nfr, dim), dtype=np.float32)).astype(np.float32)
+    first = rng.permutation(nfr - ctx + 1)[:3 * B + 17].astype(np.int32)   # shuffled windows + ragged tail
+    idx = first[:, None] + np.arange(ctx)[None, :]
+    inp = np.ascontiguousarray(feat[idx].reshape(len(first), ctx * dim))
+    tg = np.ascontiguousarray(targ[first + toff])
+    ws, bs = synth.make_weights(ls, seed=4)
+    a = pkg.BPGpu(1, 0, ls, B, *HP, ws, bs, beta, ml)
+    b = pkg.BPGpu(1, 0, ls, B, *HP, ws, bs, beta, ml)
+    assert a.train(inp, tg) == 3
+    assert b.train_frames(feat, targ, first, ctx, toff) == 3
+    for x, y in zip(a.returnWeights()[0] + a.returnWeights()[1], b.returnWeights()[0] + b.returnWeights()[1]):
+        assert np.array_equal(x, y)
+    assert a.cv_all(inp, tg) == b.cv_all_frames(feat, targ, first, ctx, toff)
+    assert np.array_equal(a.forward(inp), b.forward_frames(feat, first, ctx))
+    with pytest.raises(pkg.MlggdError, match="outside"):
+        b.train_frames(feat, targ, np.array([nfr - 3], np.int32), ctx, toff)
+    a.close()
+    b.close()
+
+
 def test_linearity_of_forward_at_full_size(pkg, synth):
     """Size-independent property at BASELINE size: with one linear layer the network output is
     linear in the input; f(a x1 + b x2) = a f(x1) + b f(x2) - (a+b-1) bias."""
@@ -168,6 +197,15 @@ def test_bptrain_sigmoid_executable(pkg, pyoracle, tmp_path):
     for line in ("Get pfile info over: Training data has %d frames, %d sentences." % (nfr, len(lens)), "Total cost time:",
                  "Saving over.", "Starting CV."):
         assert line in log
+
+    # the reference-style host expansion (MLGGD_EXPANDED=1) gives the same weights file, bit for bit
+    kv2 = dict(kv, outwts_file=tmp_path / "mlp.exp.wts", log_file=tmp_path / "mlp.exp.log")
+    res = subprocess.run([exe] + ["%s=%s" % (k, v) for k, v in kv2.items()], capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, MLGGD_EXPANDED="1"))
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert open(tmp_path / "mlp.exp.wts", "rb").read() == open(tmp_path / "mlp.1.wts", "rb").read()
+    cvlines = lambda t: [l for l in t.splitlines() if l.startswith("CV")]
+    assert cvlines(open(tmp_path / "mlp.exp.log").read()) == cvlines(log)
 
     # errors: message in the log, non-zero exit status
     kv["initwts_file"] = tmp_path / "missing.wts"

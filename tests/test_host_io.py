@@ -111,6 +111,38 @@ def test_readchunk_matches_restatement_with_lrand48_order(corpus, ctx, cache, se
     io.close()
 
 
+@pytest.mark.parametrize("ctx,cache", [(5, 64), (7, 50)])
+def test_frame_stream_reader_equals_expanding_reader(corpus, ctx, cache):
+    """Readchunk_frames (raw frames + first frame per row) describes exactly the matrix Readchunk
+    expands on the host: row r == frames[first[r] : first[r]+ctx] flattened, target == frame
+    first[r]+targ_offset -- with the same lrand48 draws."""
+    toff = (ctx - 1) // 2
+    dim = corpus["dim"]
+    # lrand48 is process-global state: run the two readers one after the other (each open re-seeds)
+    a = open_io(corpus, ctx=ctx, cache=cache, toff=toff)
+    starts, total = a.plan("0-9")
+    order = a.shuffle(len(starts))
+    expanded = [a.read_chunk(ci, ctx * dim, dim, cache) for ci in order]
+    a.plan("10-11", cv=True)
+    expanded_cv = a.read_chunk(0, ctx * dim, dim, cache, cv=True)
+    a.close()
+    b = open_io(corpus, ctx=ctx, cache=cache, toff=toff)
+    b.plan("0-9")
+    assert b.shuffle(len(starts)) == order
+    for ci, (inp, tg) in zip(order, expanded):
+        feat, ftarg, first = b.read_chunk_frames(ci, dim, dim, 4000, cache)
+        assert len(first) == len(inp)
+        idx = first[:, None] + np.arange(ctx)[None, :]
+        assert np.array_equal(feat[idx].reshape(len(first), ctx * dim), inp)
+        assert np.array_equal(ftarg[first + toff], tg)
+    b.plan("10-11", cv=True)
+    feat, ftarg, first = b.read_chunk_frames(0, dim, dim, 4000, cache, cv=True)
+    idx = first[:, None] + np.arange(ctx)[None, :]
+    assert np.array_equal(feat[idx].reshape(len(first), ctx * dim), expanded_cv[0])
+    assert np.array_equal(ftarg[first + toff], expanded_cv[1])
+    b.close()
+
+
 def test_cli_and_file_errors(corpus):
     with pytest.raises(hostlib.HostError, match="Format Error"):
         hostlib.HostIO.raw(["fea_dim"])
