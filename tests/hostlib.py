@@ -232,3 +232,13 @@ def read_chunk(feat, targ, ends, starts, total_samples, sent_en, index, ctx, tof
         pos = send
         sent += 1
     return inp, tg
+
+
+class HostNorm:
+    @staticmethod
+    def read(path, dim):
+        """norm file as the trainer/decoder parse it: 'vec N', N means, 'vec N', N inverse std-devs."""
+        lines = open(path).read().split("\n")
+        mean = np.array([float(x) for x in lines[1:1 + dim]], np.float32)
+        inv = np.array([float(x) for x in lines[2 + dim:2 + 2 * dim]], np.float32)
+        return mean, inv

@@ -212,3 +212,71 @@ def test_bptrain_sigmoid_executable(pkg, pyoracle, tmp_path):
     kv["log_file"] = tmp_path / "err.log"
     res = subprocess.run([exe] + ["%s=%s" % (k, v) for k, v in kv.items()], capture_output=True, text=True, timeout=60)
     assert res.returncode == 1 and "can not open initial weights file" in open(tmp_path / "err.log").read()
+
+
+def test_dropout_training_and_cv_scaling(pkg, pyoracle, synth):
+    """a25 (BP_GPU.cu:344-355, 484-501): dropout zeroes inputs/hidden activations where u < p with
+    NO rescale in training; CV scales W by the keep-probability around each GEMM.  The random
+    stream differs from cuRAND by design, so training is checked statistically and CV exactly."""
+    ls, B = [257 * 3, 256, 256, 257], 128
+    ws, bs = synth.make_weights(ls, seed=5)
+    inp, targ = synth.make_frames(B, 257, 3, seed=6)
+    inp = np.abs(inp) + 0.5                                   # no exact zeros in the data
+    eng = pkg.BPGpu(77, 0, ls, B, 0.0, 0.0, 0.0, ws, bs, 2.0, 0, dropoutflag=1, visible_omit=0.2, hid_omit=0.5)
+    eng.train(inp, targ)                                      # lrate 0: weights stay, activations observable
+    y1 = eng.debug_tensor("y", 1)
+    frac_hidden = float((y1 == 0).mean())
+    assert abs(frac_hidden - 0.5) < 0.02, frac_hidden         # sigmoid outputs are never exactly 0
+    yt1 = eng.debug_tensor("yt", 1)
+    assert np.array_equal(y1 == 0, yt1 == 0)                  # both layouts dropped identically
+    # CV: forward with W scaled by keep-prob == oracle forward on pre-scaled weights
+    out = eng.forward(inp)
+    keep = [0.8, 0.5, 0.5]
+    ora = pyoracle.OracleNet(ls, B, 0.0, 0.0, 0.0, 2.0, 0, [w * k for w, k in zip(ws, keep)], bs)
+    want = ora.cv_forward(inp)
+    assert np.abs(out - want).max() / np.abs(want).max() < 2e-4
+    w_after, _ = eng.returnWeights()
+    for a, b in zip(w_after, ws):
+        assert np.abs(a - b).max() <= 2e-7 * np.abs(b).max()  # scale / unscale round trip
+    # a different seed gives a different mask
+    eng2 = pkg.BPGpu(78, 0, ls, B, 0.0, 0.0, 0.0, ws, bs, 2.0, 0, dropoutflag=1, visible_omit=0.2, hid_omit=0.5)
+    eng2.train(inp, targ)
+    assert not np.array_equal(eng2.debug_tensor("y", 1) == 0, y1 == 0)
+    eng.close()
+    eng2.close()
+
+
+def test_enhance_lps_tool_matches_decode_m_math(tmp_path):
+    """the inference tool vs a float64 restatement of Test_code/decode.m +
+    frame_expand.m (edge-replicated 7-frame context, sigmoid MLP, de-normalisation, HTK out)."""
+    import struct
+    subprocess.check_call(["make", "-C", hostlib.HOST, "-s"])
+    rng = np.random.default_rng(21)
+    dim, ctx, n = 257, 7, 168
+    ls = [dim * ctx, 96, 80, dim]
+    ws = [rng.normal(0, 0.05, (ls[i], ls[i + 1])).astype(np.float32) for i in range(3)]
+    bs = [rng.normal(0, 0.1, ls[i + 1]).astype(np.float32) for i in range(3)]
+    hostlib.write_wts(str(tmp_path / "mlp.wts"), ws, bs)
+    mean = rng.normal(10, 2, dim).astype(np.float32)
+    inv = (1.0 / rng.uniform(2, 4, dim)).astype(np.float32)
+    hostlib.write_norm(str(tmp_path / "n.norm"), mean, inv)
+    lps = rng.normal(10, 3, (n, dim)).astype(np.float32)
+    with open(tmp_path / "noisy.lps", "wb") as f:                      # HTK big-endian, as Wav2LPS_be writes it
+        f.write(struct.pack(">iihh", n, 160000, dim * 4, 9) + lps.astype(">f4").tobytes())
+    res = subprocess.run([os.path.join(hostlib.HOST, "enhance_lps"), "wts=%s" % (tmp_path / "mlp.wts"),
+                          "norm_file=%s" % (tmp_path / "n.norm"), "in=%s" % (tmp_path / "noisy.lps"),
+                          "out=%s" % (tmp_path / "out.htk"), "fea_context=7"], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stdout + res.stderr
+    raw = open(tmp_path / "out.htk", "rb").read()
+    assert struct.unpack(">iihh", raw[:12]) == (n, 160000, dim * 4, 9)
+    got = np.frombuffer(raw[12:], ">f4").reshape(n, dim).astype(np.float64)
+    norm_mean, norm_inv = hostlib.HostNorm.read(str(tmp_path / "n.norm"), dim)   # what the tool parsed (text file)
+    x = (lps - norm_mean) * norm_inv                                   # decode.m:31-33
+    idx = np.clip(np.arange(n)[:, None] + np.arange(-3, 4)[None, :], 0, n - 1)   # frame_expand.m
+    a = x[idx].reshape(n, ctx * dim).astype(np.float64)
+    for i in range(3):
+        a = a @ ws[i].astype(np.float64) + bs[i]
+        if i < 2:
+            a = 1.0 / (1.0 + np.exp(-a))
+    want = a / norm_inv + norm_mean                                    # decode.m:59-61
+    assert np.abs(got - want).max() < 2e-4 * np.abs(want).max()
