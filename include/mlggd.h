@@ -153,6 +153,8 @@ int mlggd_last_train_ms(mlggd_handle h, float *ms, int *steps);
 int mlggd_profile_select(mlggd_handle h, const char *kernel_class, int layer, int max_launches);
 int mlggd_profile_stride(mlggd_handle h, int every_nth_step); /* bracket only every n-th step (default 1) */
 int mlggd_profile_read(mlggd_handle h, float *mean_usec, int *launches);
+/* cost of one event bracket itself (in-process calibration: 2*T(one kernel) - T(two kernels)) */
+int mlggd_profile_overhead(mlggd_handle h, float *usec);
 int mlggd_kernel_work(mlggd_handle h, const char *kernel_class, int layer, double *flops, double *bytes);
 
 /* Diagnostic (not part of the reference surface): in-kernel phase stamps of the NEXT launch of

@@ -43,7 +43,8 @@ EXPORTS = [
     "mlggd_cv_loglik", "mlggd_cv_all", "mlggd_forward", "mlggd_get_weights", "mlggd_set_weights",
     "mlggd_get_scalefactor", "mlggd_set_scalefactor", "mlggd_set_lrate", "mlggd_gamma",
     "mlggd_debug_tensor", "mlggd_comm_unique_id", "mlggd_comm_init", "mlggd_last_train_ms",
-    "mlggd_profile_select", "mlggd_profile_stride", "mlggd_profile_read", "mlggd_kernel_work",
+    "mlggd_profile_select", "mlggd_profile_stride", "mlggd_profile_read", "mlggd_profile_overhead",
+    "mlggd_kernel_work",
     "mlggd_debug_stamp_select", "mlggd_debug_stamp_read",
     "mlggd_load_frames", "mlggd_train_frames", "mlggd_cv_all_frames", "mlggd_forward_frames",
     "mlggd_alloc_pinned", "mlggd_free_pinned",
@@ -98,6 +99,7 @@ def load():
     L.mlggd_profile_select.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int]
     L.mlggd_profile_stride.argtypes = [C.c_void_p, C.c_int]
     L.mlggd_profile_read.argtypes = [C.c_void_p, _fp, C.POINTER(C.c_int)]
+    L.mlggd_profile_overhead.argtypes = [C.c_void_p, _fp]
     L.mlggd_kernel_work.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_double),
                                     C.POINTER(C.c_double)]
     L.mlggd_debug_stamp_select.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
@@ -366,6 +368,11 @@ class BPGpu:
         us, n = C.c_float(0), C.c_int(0)
         _check(load().mlggd_profile_read(self._h, C.byref(us), C.byref(n)))
         return us.value, n.value
+
+    def profile_overhead(self):
+        us = C.c_float(0)
+        _check(load().mlggd_profile_overhead(self._h, C.byref(us)))
+        return us.value
 
     def kernel_work(self, kernel_class, layer=0):
         f, b = C.c_double(0), C.c_double(0)

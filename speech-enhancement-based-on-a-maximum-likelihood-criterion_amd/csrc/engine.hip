@@ -1209,6 +1209,45 @@ int mlggd_debug_stamp_read(mlggd_handle e, long long *out, int cap_blocks, int *
     return MLGGD_OK;
 }
 
+// Cost of one HIP-event bracket on the engine's stream, calibrated in-process: a kernel
+// bracketed once measures overhead + t, bracketed twice back to back overhead + 2t, so
+// overhead = 2*T1 - T2.  Uses the (idempotent) input-staging kernel on the resident chunk.
+int mlggd_profile_overhead(mlggd_handle e, float *usec) {
+    if (!e || !usec) return fail(MLGGD_ERR_ARG, "NULL argument");
+    if (e->chunk_frames < 1) return fail(MLGGD_ERR_STATE, "no resident chunk");
+    HIPCHK(hipSetDevice(e->device));
+    const int reps = 24;
+    std::vector<hipEvent_t> ev(4 * reps);
+    for (auto &x : ev) HIPCHK(hipEventCreate(&x));
+    const Bunch bn = bunch_at(e, 0);
+    const int frames = e->chunk_frames < e->B ? e->chunk_frames : e->B;
+    const int saved = e->prof_class;
+    e->prof_class = -1;
+    for (int r = 0; r < reps; r++) {
+        HIPCHK(hipEventRecord(ev[4 * r], e->stream));
+        CHK(run_transpose(e, bn, frames));
+        HIPCHK(hipEventRecord(ev[4 * r + 1], e->stream));
+        HIPCHK(hipEventRecord(ev[4 * r + 2], e->stream));
+        CHK(run_transpose(e, bn, frames));
+        CHK(run_transpose(e, bn, frames));
+        HIPCHK(hipEventRecord(ev[4 * r + 3], e->stream));
+    }
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->prof_class = saved;
+    double t1 = 0, t2 = 0;
+    for (int r = 4; r < reps; r++) {  // first reps warm up
+        float a = 0, b = 0;
+        HIPCHK(hipEventElapsedTime(&a, ev[4 * r], ev[4 * r + 1]));
+        HIPCHK(hipEventElapsedTime(&b, ev[4 * r + 2], ev[4 * r + 3]));
+        t1 += a;
+        t2 += b;
+    }
+    for (auto &x : ev) hipEventDestroy(x);
+    const double ov = (2 * t1 - t2) / (reps - 4) * 1000.0;
+    *usec = ov > 0 ? (float)ov : 0.0f;
+    return MLGGD_OK;
+}
+
 // Static description of the launch plan (DESIGN.md "kernels"): algorithmic FLOPs and bytes of
 // one launch of the (class, layer) kernel; layer 0 = sum over layers.
 int mlggd_kernel_work(mlggd_handle e, const char *kernel_class, int layer, double *flops, double *bytes) {
