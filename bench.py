@@ -121,7 +121,7 @@ def main():
         us = max(us_raw - bracket_us, 1e-3)
         # the dominant kernel (largest share of the step in profiles/): k_dwp, the weight-gradient GEMM
         # with the fused momentum / weight-decay / bias update; mean over its launches (all layers)
-        nl = len(ls) - 1
+        nl = eng.dw_launches_per_step()  # 1: all layers share one persistent launch (single GPU)
         fl = eng.kernel_work("dw", 0)[0] / nl
         by = eng.kernel_work("dw", 0)[1] / nl
         if nlaunch > 0 and us > 0:
@@ -136,7 +136,9 @@ def main():
             # which roof binds this kernel: arithmetic intensity against the machine balance
             # 157.3 TFLOP/s / 8 TB/s = 19.7 FLOP/B (at B = 128 the kernel moves 16 B per 2*B flops -> HBM)
             gbps = by / (us * 1e-6) / 1e9
-            name = "k_dwp<%d,true> (persistent dW GEMM + fused momentum/weight-decay/bias update)" % max(1, ((B + 31) // 32 * 32) // 64)
+            name = "k_dwp<%d,%s> (persistent dW GEMM + fused momentum/weight-decay/bias update, %s)" % (
+                max(1, ((B + 31) // 32 * 32) // 64), "true" if world == 1 else "false",
+                "all layers in one launch" if nl == 1 else "one launch per layer")
             if fl / by < MFMA_F32_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBPS * 1e9):
                 roofline = {"bound": "hbm", "kernel": name, "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS,
                             "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": traffic}

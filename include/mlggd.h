@@ -156,6 +156,9 @@ int mlggd_profile_read(mlggd_handle h, float *mean_usec, int *launches);
 /* cost of one event bracket itself (in-process calibration: 2*T(one kernel) - T(two kernels)) */
 int mlggd_profile_overhead(mlggd_handle h, float *usec);
 int mlggd_kernel_work(mlggd_handle h, const char *kernel_class, int layer, double *flops, double *bytes);
+/* how many launches of the weight-gradient/update kernel one training step issues: 1 when the
+ * layers share one persistent launch (single GPU), numlayers-1 otherwise */
+int mlggd_dw_launches_per_step(mlggd_handle h, int *launches);
 
 /* Diagnostic (not part of the reference surface): in-kernel phase stamps of the NEXT launch of
  * (class "fwd"|"dx"|"dw", layer): 8 int64 slots per workgroup in 100 MHz ticks

@@ -44,7 +44,7 @@ EXPORTS = [
     "mlggd_get_scalefactor", "mlggd_set_scalefactor", "mlggd_set_lrate", "mlggd_gamma",
     "mlggd_debug_tensor", "mlggd_comm_unique_id", "mlggd_comm_init", "mlggd_last_train_ms",
     "mlggd_profile_select", "mlggd_profile_stride", "mlggd_profile_read", "mlggd_profile_overhead",
-    "mlggd_kernel_work",
+    "mlggd_kernel_work", "mlggd_dw_launches_per_step",
     "mlggd_debug_stamp_select", "mlggd_debug_stamp_read",
     "mlggd_load_frames", "mlggd_train_frames", "mlggd_cv_all_frames", "mlggd_forward_frames",
     "mlggd_alloc_pinned", "mlggd_free_pinned",
@@ -102,6 +102,7 @@ def load():
     L.mlggd_profile_overhead.argtypes = [C.c_void_p, _fp]
     L.mlggd_kernel_work.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_double),
                                     C.POINTER(C.c_double)]
+    L.mlggd_dw_launches_per_step.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     L.mlggd_debug_stamp_select.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     L.mlggd_debug_stamp_read.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.c_int, C.POINTER(C.c_int)]
     _ip = C.POINTER(C.c_int32)
@@ -379,6 +380,10 @@ class BPGpu:
         _check(load().mlggd_kernel_work(self._h, kernel_class.encode(), int(layer), C.byref(f), C.byref(b)))
         return f.value, b.value
 
+    def dw_launches_per_step(self):
+        n = C.c_int(0)
+        _check(load().mlggd_dw_launches_per_step(self._h, C.byref(n)))
+        return n.value
 
     def stamp_select(self, kernel_class, layer):
         _check(load().mlggd_debug_stamp_select(self._h, kernel_class.encode(), int(layer)))

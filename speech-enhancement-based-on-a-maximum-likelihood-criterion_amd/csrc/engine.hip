@@ -131,7 +131,7 @@ struct mlggd_engine {
     int fdim = 0, toff = 0, raw_frames = 0;
     unsigned step_counter = 0;
     // launch-plan knobs (defaults chosen from measurements; env overrides for A/B runs)
-    int fwd_nw = 8, dx_nw = 8, dw_tile = 1, dw_persist = 1, dwp_per_cu = 2;  // dw_tile 0 = auto
+    int fwd_nw = 8, dx_nw = 8, dw_tile = 1, dw_persist = 1, dwp_per_cu = 2, dw_merge = 1, loss_fuse = 1, tile_map = 0;  // dw_tile 0 = auto
 
     // data parallel
     int world = 1, rank = 0;
@@ -240,6 +240,7 @@ static FwdArgs fwd_args(mlggd_engine *e, int l, float *Yrow_out) {
     a.n_tiles = e->lsp[l] / 32;
     a.b_tiles = e->Bp / 32;
     a.S = (l == e->L - 1) ? e->S_out : 1;
+    a.map = e->tile_map;
     return a;
 }
 
@@ -255,6 +256,7 @@ static DxArgs dx_args(mlggd_engine *e, int l) {
     a.Bp = e->Bp;
     a.k_tiles = e->lsp[l - 1] / 32;
     a.b_tiles = e->Bp / 32;
+    a.map = e->tile_map;
     return a;
 }
 
@@ -400,19 +402,45 @@ static int dwp_grid(mlggd_engine *e, int ntiles) {
     int grid = 256 * (e->dwp_per_cu > 0 ? e->dwp_per_cu : 2);
     return grid > ntiles ? ntiles : grid;
 }
+// jobs for layers lhi, lhi-1, ..., llo in one launch
+static_assert(DWP_MAXJOBS >= MLGGD_MAXLAYER, "job table too small");
+static DwpJobs dwp_jobs(mlggd_engine *e, int lhi, int llo, const float *in_rows, float nf) {
+    DwpJobs J;
+    memset(&J, 0, sizeof(J));
+    int nj = 0, end = 0;
+    for (int l = lhi; l >= llo; l--) {
+        J.job[nj] = dwp_args(e, l, in_rows, e->Y[l - 1], nf);
+        end += J.job[nj].ntiles;
+        J.tile_end[nj++] = end;
+    }
+    J.njobs = nj;
+    J.total = end;
+    return J;
+}
 template <int H>
-static int launch_dwp(mlggd_engine *e, int l, const float *in_rows, bool fused, float nf, hipStream_t st) {
-    DwpArgs da = dwp_args(e, l, in_rows, e->Y[l - 1], nf);
+static int launch_dwp_t(mlggd_engine *e, const DwpJobs &J, bool fused, hipStream_t st) {
     const size_t lds = dwp_lds_floats() * sizeof(float);
-    const int grid = dwp_grid(e, da.ntiles);
+    const int grid = dwp_grid(e, J.total);
     if (fused) {
         CHK(ensure_lds(k_dwp<H, true>, lds));
-        hipLaunchKernelGGL((k_dwp<H, true>), dim3(grid), dim3(256), lds, st, da);
+        hipLaunchKernelGGL((k_dwp<H, true>), dim3(grid), dim3(256), lds, st, J);
     } else {
         CHK(ensure_lds(k_dwp<H, false>, lds));
-        hipLaunchKernelGGL((k_dwp<H, false>), dim3(grid), dim3(256), lds, st, da);
+        hipLaunchKernelGGL((k_dwp<H, false>), dim3(grid), dim3(256), lds, st, J);
     }
     return launch_check("k_dwp");
+}
+static bool dwp_usable(const mlggd_engine *e) {
+    const int Hh = e->Bp / 64;
+    return e->dw_persist && e->Bp % 64 == 0 && (Hh == 1 || Hh == 2 || Hh == 4 || Hh == 8);
+}
+static int launch_dwp(mlggd_engine *e, const DwpJobs &J, bool fused, hipStream_t st) {
+    switch (e->Bp / 64) {
+    case 1: return launch_dwp_t<1>(e, J, fused, st);
+    case 2: return launch_dwp_t<2>(e, J, fused, st);
+    case 4: return launch_dwp_t<4>(e, J, fused, st);
+    default: return launch_dwp_t<8>(e, J, fused, st);
+    }
 }
 
 static BiasJobs make_bias_jobs(mlggd_engine *e) {
@@ -451,7 +479,12 @@ static int run_step(mlggd_engine *e, const Bunch &bn) {
     {
         ProfScope ps(e, KC_LOSS, 0);
         const size_t lds = (size_t)(32 * (Bp + 1) + 32) * sizeof(float);
-        {
+        if (ML != 1 && e->loss_fuse) {
+            hipLaunchKernelGGL(k_loss_norm, dim3((e->Dp / 32) * b_tiles), dim3(256), 0, e->stream, e->slab, e->S_out,
+                               e->bias[L - 1], targ_rows, B, e->D, e->Dp, Bp, e->cfg.shapefactor, inv_n, e->outT, e->eT,
+                               e->dEdXt[L - 1], e->dEdX[L - 1], b_tiles, bn.first, e->toff);
+            CHK(launch_check("k_loss_norm"));
+        } else {
             hipLaunchKernelGGL(k_loss_err, dim3((e->Dp / 32) * b_tiles), dim3(256), 0, e->stream, e->slab, e->S_out,
                                e->bias[L - 1], targ_rows, B, e->D, e->Dp, Bp, e->cfg.shapefactor, ML == 1 ? 1 : 0,
                                e->outT, e->eT, e->pT, b_tiles, bn.first, e->toff);
@@ -471,6 +504,10 @@ static int run_step(mlggd_engine *e, const Bunch &bn) {
     }
     const bool two = e->two_streams != 0;
     hipStream_t dws = two ? e->dw_stream : e->stream;
+    // single GPU: every dW(l) only needs dEdX_l and Y_{l-1}, so one persistent launch walks the
+    // tiles of all layers after the last dX (the data-parallel path keeps one launch per layer so
+    // that the all-reduce of layer l overlaps the rest of the backward pass)
+    const bool merged = !dp && !two && e->dw_merge && dwp_usable(e);
     for (int l = L - 1; l >= 1; l--) {
         const int Kp = e->lsp[l - 1], Np = e->lsp[l];
         if (l != 1) {
@@ -492,17 +529,14 @@ static int run_step(mlggd_engine *e, const Bunch &bn) {
             HIPCHK(hipEventRecord(e->ev_dx[l], e->stream));
             HIPCHK(hipStreamWaitEvent(dws, e->ev_dx[l], 0));
         }
+        if (merged) continue;  // all layers' dW + update run as one launch after the last dX
         {
             const long tiles128 = (long)((Kp + 127) / 128) * ((Np + 127) / 128);
             const bool big = e->dw_tile == 0 ? tiles128 >= 192 : e->dw_tile == 2;
             ProfScope ps(e, KC_DW, l, dws);
-            const int Hh = e->Bp / 64;
-            if (e->dw_persist && e->Bp % 64 == 0 && (Hh == 1 || Hh == 2 || Hh == 4 || Hh == 8)) {
-                if (Hh == 1) CHK(launch_dwp<1>(e, l, in_rows, !dp, nf, dws));
-                else if (Hh == 2) CHK(launch_dwp<2>(e, l, in_rows, !dp, nf, dws));
-                else if (Hh == 4) CHK(launch_dwp<4>(e, l, in_rows, !dp, nf, dws));
-                else CHK(launch_dwp<8>(e, l, in_rows, !dp, nf, dws));
-            } else if (big)
+            if (dwp_usable(e))
+                CHK(launch_dwp(e, dwp_jobs(e, l, l, in_rows, nf), !dp, dws));
+            else if (big)
                 CHK(launch_dw<2>(e, l, in_rows, !dp, nf, dws));
             else
                 CHK(launch_dw<1>(e, l, in_rows, !dp, nf, dws));
@@ -513,6 +547,10 @@ static int run_step(mlggd_engine *e, const Bunch &bn) {
             NCCLCHK(g_rccl.AllReduce(e->G[l], e->G[l], (size_t)Kp * Np, 7, 0, e->comm, e->comm_stream));
             HIPCHK(hipEventRecord(e->ev_red[l], e->comm_stream));
         }
+    }
+    if (merged) {
+        ProfScope ps(e, KC_DW, 1, dws);
+        CHK(launch_dwp(e, dwp_jobs(e, L - 1, 1, in_rows, nf), true, dws));
     }
     if (dp) {
         // bias gradients were written by the dw kernels; ev_grad[1] is the last of them
@@ -590,6 +628,9 @@ int mlggd_create(const mlggd_config *cfg, const float *const *weights, const flo
     if (const char *v = getenv("MLGGD_TWO_STREAMS")) e->two_streams = atoi(v);
     if (const char *v = getenv("MLGGD_DW_PERSIST")) e->dw_persist = atoi(v);
     if (const char *v = getenv("MLGGD_DWP_PER_CU")) e->dwp_per_cu = atoi(v);
+    if (const char *v = getenv("MLGGD_DW_MERGE")) e->dw_merge = atoi(v);
+    if (const char *v = getenv("MLGGD_LOSS_FUSE")) e->loss_fuse = atoi(v);
+    if (const char *v = getenv("MLGGD_TILE_MAP")) e->tile_map = atoi(v);
     *out = e;  // so the caller can destroy on failure
 
     HIPCHK(hipSetDevice(e->device));
@@ -1250,6 +1291,13 @@ int mlggd_profile_overhead(mlggd_handle e, float *usec) {
 
 // Static description of the launch plan (DESIGN.md "kernels"): algorithmic FLOPs and bytes of
 // one launch of the (class, layer) kernel; layer 0 = sum over layers.
+int mlggd_dw_launches_per_step(mlggd_handle e, int *launches) {
+    if (!e || !launches) return fail(MLGGD_ERR_ARG, "NULL argument");
+    const bool merged = e->comm == nullptr && !e->two_streams && e->dw_merge && dwp_usable(e);
+    *launches = merged ? 1 : e->L - 1;
+    return MLGGD_OK;
+}
+
 int mlggd_kernel_work(mlggd_handle e, const char *kernel_class, int layer, double *flops, double *bytes) {
     if (!e || !kernel_class) return fail(MLGGD_ERR_ARG, "NULL argument");
     double f = 0, by = 0;

@@ -28,10 +28,11 @@ __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (
 // ids that are equal mod 8 and adjacent in dispatch order, so they land on one XCD and the
 // tile is fetched from HBM/MALL once and re-read from that XCD's L2 (speed only; any
 // placement is correct).
-__device__ __forceinline__ void tile_of_block(int id, int u_tiles, int b_tiles, int &ut, int &bt) {
-    if ((u_tiles & 7) == 0) {
+__device__ __forceinline__ void tile_of_block(int id, int u_tiles, int b_tiles, int &ut, int &bt, int map = 0) {
+    if ((u_tiles & 7) == 0 && map != 2) {
         const int xcd = id & 7, slot = id >> 3;
-        ut = xcd + 8 * (slot / b_tiles);
+        // map 0: an XCD owns unit tiles xcd, xcd+8, ...; map 1: a contiguous run of u_tiles/8 tiles
+        ut = map == 1 ? xcd * (u_tiles >> 3) + slot / b_tiles : xcd + 8 * (slot / b_tiles);
         bt = slot % b_tiles;
     } else {
         ut = id / b_tiles;
@@ -90,7 +91,7 @@ enum { FWD_SIGMOID = 0, FWD_SLAB = 1 };
 struct FwdArgs {
     const float *W, *Yt_in, *bias;
     float *Yt_out, *Y_out, *slab;
-    int Kp, Np, Bp, N, n_tiles, b_tiles, S;
+    int Kp, Np, Bp, N, n_tiles, b_tiles, S, map;
 };
 // LDS floats needed by fwd_body<.,NW>: staging/reduction tiles + the 32x33 transposition tile
 template <int NW> constexpr int fwd_lds_floats() { return NW * 2048 + 32 * 33; }
@@ -112,7 +113,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &A, const int bid, float 
         id /= S;
     }
     int nt, bt;
-    tile_of_block(id, n_tiles, b_tiles, nt, bt);
+    tile_of_block(id, n_tiles, b_tiles, nt, bt, A.map);
     const int n0 = nt * 32, b0 = bt * 32;
 
     // k-pairs of this wave: slot = s*NW+wave of S*NW slots over Kp/2 pairs
@@ -247,7 +248,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &A, const int bid, float 
 struct DxArgs {
     const float *W, *dEdXt, *Yt_prev;
     float *dEdXt_prev, *dEdX_prev;
-    int Kp, Np, Bp, k_tiles, b_tiles;
+    int Kp, Np, Bp, k_tiles, b_tiles, map;
 };
 template <int NW> constexpr int dx_lds_floats() { return NW * (32 * DX_LDW + 2048) + 32 * 33; }
 
@@ -263,7 +264,7 @@ __device__ __forceinline__ void dx_body(const DxArgs &A, const int bid, float *s
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
     const int i = lane & 31, h = lane >> 5;
     int kt, bt;
-    tile_of_block(bid, k_tiles, b_tiles, kt, bt);
+    tile_of_block(bid, k_tiles, b_tiles, kt, bt, A.map);
     const int k0 = kt * 32, b0 = bt * 32;
 
     const int Q = Np >> 2;             // quads of 4 consecutive n
@@ -597,28 +598,57 @@ struct DwpArgs {
     int ldA, K, N, Kp, Np, B, n_wg, ntiles;
     float nf, mom, lr, wc;
 };
+// One launch may walk the tiles of several layers (every dW(l) only needs dEdX_l and Y_{l-1}, both
+// final once the last dX has run): job j owns the global tile numbers [tile_end[j-1], tile_end[j]).
+constexpr int DWP_MAXJOBS = 10;
+struct DwpJobs {
+    DwpArgs job[DWP_MAXJOBS];
+    int tile_end[DWP_MAXJOBS];
+    int njobs, total;
+};
 constexpr int dwp_lds_floats() { return 2 * 8192; }
 
-// bid / nblocks: this workgroup's index and the number of workgroups walking the tiles (the
-// body is written so that it could share a launch with other work)
+// everything the pipeline needs to know about one 64x64 tile (wave-uniform -> SGPRs)
+struct DwpTile {
+    const float *Yrow, *dEdX;
+    float *Wt, *delta, *G, *bias, *dbias, *gb;
+    int ldA, K, N, Np, k0, n0;
+    unsigned szA, szB, szW;  // descriptor sizes in bytes; 0 = "no such tile": loads give 0, stores are dropped
+};
+__device__ __forceinline__ DwpTile dwp_locate(const DwpJobs &J, const int t, const int Bp) {
+    DwpTile T;
+    int j = 0, first = 0;
+#pragma unroll 1
+    for (int q = 0; q + 1 < J.njobs; q++)
+        if (t >= J.tile_end[q]) {
+            j = q + 1;
+            first = J.tile_end[q];
+        }
+    const DwpArgs &A = J.job[j];
+    const bool valid = t < J.total;
+    const int tl = valid ? t - first : 0;
+    T.Yrow = A.Yrow; T.dEdX = A.dEdX; T.Wt = A.Wt; T.delta = A.delta; T.G = A.G;
+    T.bias = A.bias; T.dbias = A.dbias; T.gb = A.gb;
+    T.ldA = A.ldA; T.K = A.K; T.N = A.N; T.Np = A.Np;
+    T.k0 = (tl / A.n_wg) * 64;
+    T.n0 = (tl % A.n_wg) * 64;
+    T.szA = valid ? (unsigned)Bp * A.ldA * 4u : 0u;
+    T.szB = valid ? (unsigned)Bp * A.Np * 4u : 0u;
+    T.szW = valid ? (unsigned)A.Kp * A.Np * 4u : 0u;
+    return T;
+}
+
+// bid / nblocks: this workgroup's index and the number of workgroups walking the tiles
 template <int H, bool FUSED>
-__device__ __forceinline__ void dwp_body(const DwpArgs &A, const int bid, const int nblocks, float *lds) {
-    const float *__restrict__ Yrow = A.Yrow, *__restrict__ dEdX = A.dEdX;
-    float *__restrict__ Wt = A.Wt, *__restrict__ delta = A.delta, *__restrict__ G = A.G;
-    float *__restrict__ bias = A.bias, *__restrict__ dbias = A.dbias, *__restrict__ gb = A.gb;
-    const int ldA = A.ldA, K = A.K, N = A.N, Kp = A.Kp, Np = A.Np, B = A.B, n_wg = A.n_wg, ntiles = A.ntiles;
-    const float nf = A.nf, mom = A.mom, lr = A.lr, wc = A.wc;
+__device__ __forceinline__ void dwp_body(const DwpJobs &J, const int bid, const int nblocks, float *lds) {
+    const int B = J.job[0].B;
+    const float nf = J.job[0].nf, mom = J.job[0].mom, lr = J.job[0].lr, wc = J.job[0].wc;
     constexpr int OOB = 0x7FFFFF00;  // byte offset beyond every descriptor: load -> 0, store dropped
     constexpr int PPU = 8 / H;       // W/delta prefetch loads per unit (8 per tile and lane)
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
     const int i = lane & 31, h5 = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
     const int Bp = 64 * H;
-
-    const size_t szA = (size_t)Bp * ldA * 4, szB = (size_t)Bp * Np * 4, szW = (size_t)Kp * Np * 4;
-    const rsrc_t rA = make_rsrc(Yrow, szA), rB = make_rsrc(dEdX, szB);
-    const rsrc_t rW = make_rsrc(Wt, szW), rD = make_rsrc(delta, szW);
-    const rsrc_t rG = make_rsrc(G, FUSED ? 0 : szW);
 
     const int scol = tid & 15, srow = tid >> 4;  // staging: 16 float4 per 64-float row, 16 rows per pass
     const int ec = lane & 7, er = lane >> 3;     // epilogue: 8 float4 per 32-float wave-tile row
@@ -631,15 +661,16 @@ __device__ __forceinline__ void dwp_body(const DwpArgs &A, const int bid, const 
     float bsum = 0.0f;
 
     int t = bid;
-    if (t >= ntiles) return;
-    int k0 = (t / n_wg) * 64, n0 = (t % n_wg) * 64;
+    if (t >= J.total) return;
+    DwpTile tc = dwp_locate(J, t, Bp);
 
-#define DWP_LOAD_UNIT(RA, RB, K0, N0, HH)                                                       \
+#define DWP_LOAD_UNIT(T, HH)                                                                    \
     {                                                                                           \
+        const rsrc_t rA_ = make_rsrc(T.Yrow, T.szA), rB_ = make_rsrc(T.dEdX, T.szB);            \
         _Pragma("unroll") for (int q = 0; q < 4; q++) {                                         \
             const int row = 64 * (HH) + srow + 16 * q;                                          \
-            ra[q] = bload4(RA, (row * ldA + (K0) + 4 * scol) * 4, 0);                           \
-            rb[q] = bload4(RB, (row * Np + (N0) + 4 * scol) * 4, 0);                            \
+            ra[q] = bload4(rA_, (row * T.ldA + T.k0 + 4 * scol) * 4, 0);                        \
+            rb[q] = bload4(rB_, (row * T.Np + T.n0 + 4 * scol) * 4, 0);                         \
         }                                                                                       \
     }
 #define DWP_WRITE_UNIT(BUF)                                                                     \
@@ -650,18 +681,19 @@ __device__ __forceinline__ void dwp_body(const DwpArgs &A, const int bid, const 
             *reinterpret_cast<float4 *>(bs + (srow + 16 * q) * 64 + 4 * scol) = rb[q];          \
         }                                                                                       \
     }
-    // voffset of this lane's float4 number IT of the wave tile at (K0, N0); OOB for pad rows
-#define DWP_OFF(K0, N0, IT)                                                                     \
-    ((((K0) + 32 * wm + er + 8 * (IT)) < K && ((N0) + 32 * wn + 4 * ec) < Np)                   \
-         ? (((K0) + 32 * wm + er + 8 * (IT)) * Np + (N0) + 32 * wn + 4 * ec) * 4                \
+    // voffset of this lane's float4 number IT of the wave tile of T; OOB for pad rows
+#define DWP_OFF(T, IT)                                                                          \
+    (((T.k0 + 32 * wm + er + 8 * (IT)) < T.K && (T.n0 + 32 * wn + 4 * ec) < T.Np)               \
+         ? ((T.k0 + 32 * wm + er + 8 * (IT)) * T.Np + T.n0 + 32 * wn + 4 * ec) * 4              \
          : OOB)
-#define DWP_PREFETCH(PW, PD, RW, RD, K0, N0, HH)                                                \
+#define DWP_PREFETCH(PW, PD, T, HH)                                                             \
     {                                                                                           \
         if (FUSED) {                                                                            \
+            const rsrc_t rW_ = make_rsrc(T.Wt, T.szW), rD_ = make_rsrc(T.delta, T.szW);         \
             _Pragma("unroll") for (int jj = 0; jj < PPU; jj++) {                                \
                 const int j = (HH)*PPU + jj;                                                    \
-                if (j < 4) PW[j] = bload4(RW, DWP_OFF(K0, N0, j), 0);                           \
-                else PD[j - 4] = bload4(RD, DWP_OFF(K0, N0, j - 4), 0);                         \
+                if (j < 4) PW[j] = bload4(rW_, DWP_OFF(T, j), 0);                               \
+                else PD[j - 4] = bload4(rD_, DWP_OFF(T, j - 4), 0);                             \
             }                                                                                   \
         }                                                                                       \
     }
@@ -673,7 +705,7 @@ __device__ __forceinline__ void dwp_body(const DwpArgs &A, const int bid, const 
     }
 #define DWP_BIAS(BUF, HH)                                                                       \
     {                                                                                           \
-        if (k0 == 0 && tid < 64) {                                                              \
+        if (tc.k0 == 0 && tid < 64) {                                                           \
             const float *col = lds + (BUF)*8192 + 4096 + tid;                                   \
             int bend = B - 64 * (HH);                                                           \
             bend = bend < 64 ? bend : 64;                                                       \
@@ -692,16 +724,16 @@ __device__ __forceinline__ void dwp_body(const DwpArgs &A, const int bid, const 
     }
 #define DWP_EPILOGUE(BUF, PW, PD)                                                               \
     {                                                                                           \
-        if (k0 == 0 && tid < 64) {                                                              \
-            const int n = n0 + tid;                                                             \
-            if (n < N) {                                                                        \
+        if (tc.k0 == 0 && tid < 64) {                                                           \
+            const int n = tc.n0 + tid;                                                          \
+            if (n < tc.N) {                                                                     \
                 if (FUSED) {                                                                    \
-                    const float bv = bias[n];                                                   \
-                    const float d = mom * dbias[n] - lr * (bsum / nf + 0.0f * bv);              \
-                    dbias[n] = d;                                                               \
-                    bias[n] = d + 1.0f * bv;                                                    \
+                    const float bv = tc.bias[n];                                                \
+                    const float d = mom * tc.dbias[n] - lr * (bsum / nf + 0.0f * bv);           \
+                    tc.dbias[n] = d;                                                            \
+                    tc.bias[n] = d + 1.0f * bv;                                                 \
                 } else {                                                                        \
-                    gb[n] = bsum;                                                               \
+                    tc.gb[n] = bsum;                                                            \
                 }                                                                               \
             }                                                                                   \
         }                                                                                       \
@@ -709,9 +741,11 @@ __device__ __forceinline__ void dwp_body(const DwpArgs &A, const int bid, const 
         float *Tw = lds + (BUF)*8192 + wave * 1024;                                             \
         _Pragma("unroll") for (int r = 0; r < 16; r++) Tw[acc_row(r, lane) * 32 + i] = acc[r];  \
         __builtin_amdgcn_wave_barrier();                                                        \
+        const rsrc_t rWc = make_rsrc(tc.Wt, FUSED ? tc.szW : 0), rDc = make_rsrc(tc.delta, FUSED ? tc.szW : 0); \
+        const rsrc_t rGc = make_rsrc(tc.G, FUSED ? 0 : tc.szW);                                 \
         _Pragma("unroll") for (int it = 0; it < 4; it++) {                                      \
             const float4 g = *reinterpret_cast<const float4 *>(Tw + (er + 8 * it) * 32 + 4 * ec); \
-            const int off = DWP_OFF(k0, n0, it);                                                \
+            const int off = DWP_OFF(tc, it);                                                    \
             if (FUSED) {                                                                        \
                 const float4 w = PW[it];                                                        \
                 float4 d = PD[it];                                                              \
@@ -719,86 +753,45 @@ __device__ __forceinline__ void dwp_body(const DwpArgs &A, const int bid, const 
                 d.y = mom * d.y - lr * (g.y / nf + wc * w.y);                                   \
                 d.z = mom * d.z - lr * (g.z / nf + wc * w.z);                                   \
                 d.w = mom * d.w - lr * (g.w / nf + wc * w.w);                                   \
-                bstore4(d, rD, off);                                                            \
-                bstore4(make_float4(d.x + 1.0f * w.x, d.y + 1.0f * w.y, d.z + 1.0f * w.z, d.w + 1.0f * w.w), rW, off); \
+                bstore4(d, rDc, off);                                                           \
+                bstore4(make_float4(d.x + 1.0f * w.x, d.y + 1.0f * w.y, d.z + 1.0f * w.z, d.w + 1.0f * w.w), rWc, off); \
             } else {                                                                            \
-                bstore4(g, rG, off);                                                            \
+                bstore4(g, rGc, off);                                                           \
             }                                                                                   \
         }                                                                                       \
         _Pragma("unroll") for (int r = 0; r < 16; r++) acc[r] = 0.0f;                           \
     }
-    // one tile: PWC/PDC = this tile's W/delta registers, PWN/PDN = the next tile's
-#define DWP_TILE(PWC, PDC, PWN, PDN)                                                            \
+    // one tile whose first unit sits in LDS buffer BASE: PWC/PDC = this tile's W/delta registers,
+    // PWN/PDN = the next tile's (an invalid next tile has empty descriptors: its loads cost nothing)
+#define DWP_TILE(PWC, PDC, PWN, PDN, BASE)                                                      \
     {                                                                                           \
-        const int tn = t + nblocks;                                                      \
-        const bool has_next = tn < ntiles;                                                      \
-        const int k0n = has_next ? (tn / n_wg) * 64 : k0, n0n = has_next ? (tn % n_wg) * 64 : n0; \
-        const rsrc_t rAn = make_rsrc(Yrow, has_next ? szA : 0), rBn = make_rsrc(dEdX, has_next ? szB : 0); \
-        const rsrc_t rWn = make_rsrc(Wt, has_next ? szW : 0), rDn = make_rsrc(delta, has_next ? szW : 0);  \
+        const int tnext = t + nblocks;                                                          \
+        const DwpTile tn = dwp_locate(J, tnext, Bp);                                            \
         _Pragma("unroll") for (int hh = 0; hh < H; hh++) {                                      \
-            const int buf = hh & 1;                                                             \
-            if (hh + 1 < H) DWP_LOAD_UNIT(rA, rB, k0, n0, hh + 1)                               \
-            else DWP_LOAD_UNIT(rAn, rBn, k0n, n0n, 0)                                           \
-            DWP_PREFETCH(PWN, PDN, rWn, rDn, k0n, n0n, hh)                                      \
+            const int buf = ((BASE) + hh) & 1;                                                  \
+            if (hh + 1 < H) DWP_LOAD_UNIT(tc, hh + 1)                                           \
+            else DWP_LOAD_UNIT(tn, 0)                                                           \
+            DWP_PREFETCH(PWN, PDN, tn, hh)                                                      \
             DWP_BIAS(buf, hh)                                                                   \
             DWP_MFMA(buf)                                                                       \
             if (hh == H - 1) DWP_EPILOGUE(buf, PWC, PDC)                                        \
             DWP_WRITE_UNIT(buf ^ 1)                                                             \
             __syncthreads();                                                                    \
         }                                                                                       \
-        if (!has_next) break;                                                                   \
-        t = tn;                                                                                 \
-        k0 = k0n;                                                                               \
-        n0 = n0n;                                                                               \
+        if (tnext >= J.total) break;                                                            \
+        t = tnext;                                                                              \
+        tc = tn;                                                                                \
     }
 
     // prologue: first unit into buffer 0, this tile's W/delta into set 0
-    DWP_LOAD_UNIT(rA, rB, k0, n0, 0)
-    _Pragma("unroll") for (int hh = 0; hh < H; hh++) DWP_PREFETCH(pw0, pd0, rW, rD, k0, n0, hh)
+    DWP_LOAD_UNIT(tc, 0)
+    _Pragma("unroll") for (int hh = 0; hh < H; hh++) DWP_PREFETCH(pw0, pd0, tc, hh)
     DWP_WRITE_UNIT(0)
     __syncthreads();
-    // For odd H the buffer parity flips from tile to tile; H is 1 or even here (H==1: the single
-    // unit always sits in buffer 0 because WRITE_UNIT(buf^1) of unit 0 targets buffer 1 ... so
-    // H==1 is handled by running two tiles per loop trip with swapped buffers).
+    // a tile of H units leaves its successor's first unit in buffer (BASE + H) & 1
     for (;;) {
-        if (H == 1) {
-            // tile A from buffer 0 (next unit -> buffer 1), tile B from buffer 1 (next -> buffer 0)
-            {
-                const int tn = t + nblocks;
-                const bool has_next = tn < ntiles;
-                const int k0n = has_next ? (tn / n_wg) * 64 : k0, n0n = has_next ? (tn % n_wg) * 64 : n0;
-                const rsrc_t rAn = make_rsrc(Yrow, has_next ? szA : 0), rBn = make_rsrc(dEdX, has_next ? szB : 0);
-                const rsrc_t rWn = make_rsrc(Wt, has_next ? szW : 0), rDn = make_rsrc(delta, has_next ? szW : 0);
-                DWP_LOAD_UNIT(rAn, rBn, k0n, n0n, 0)
-                DWP_PREFETCH(pw1, pd1, rWn, rDn, k0n, n0n, 0)
-                DWP_BIAS(0, 0)
-                DWP_MFMA(0)
-                DWP_EPILOGUE(0, pw0, pd0)
-                DWP_WRITE_UNIT(1)
-                __syncthreads();
-                if (!has_next) break;
-                t = tn; k0 = k0n; n0 = n0n;
-            }
-            {
-                const int tn = t + nblocks;
-                const bool has_next = tn < ntiles;
-                const int k0n = has_next ? (tn / n_wg) * 64 : k0, n0n = has_next ? (tn % n_wg) * 64 : n0;
-                const rsrc_t rAn = make_rsrc(Yrow, has_next ? szA : 0), rBn = make_rsrc(dEdX, has_next ? szB : 0);
-                const rsrc_t rWn = make_rsrc(Wt, has_next ? szW : 0), rDn = make_rsrc(delta, has_next ? szW : 0);
-                DWP_LOAD_UNIT(rAn, rBn, k0n, n0n, 0)
-                DWP_PREFETCH(pw0, pd0, rWn, rDn, k0n, n0n, 0)
-                DWP_BIAS(1, 0)
-                DWP_MFMA(1)
-                DWP_EPILOGUE(1, pw1, pd1)
-                DWP_WRITE_UNIT(0)
-                __syncthreads();
-                if (!has_next) break;
-                t = tn; k0 = k0n; n0 = n0n;
-            }
-        } else {
-            DWP_TILE(pw0, pd0, pw1, pd1)
-            DWP_TILE(pw1, pd1, pw0, pd0)
-        }
+        DWP_TILE(pw0, pd0, pw1, pd1, 0)
+        DWP_TILE(pw1, pd1, pw0, pd0, H & 1)
     }
 #undef DWP_LOAD_UNIT
 #undef DWP_WRITE_UNIT
@@ -829,8 +822,8 @@ __global__ __launch_bounds__(64 * NW) void k_dx(DxArgs A, long long *stamps) {
     dx_body<NW>(A, (int)blockIdx.x, g_dyn_lds, stamps);
 }
 template <int H, bool FUSED>
-__global__ __launch_bounds__(256) void k_dwp(DwpArgs A) {
-    dwp_body<H, FUSED>(A, (int)blockIdx.x, (int)gridDim.x, g_dyn_lds);
+__global__ __launch_bounds__(256) void k_dwp(DwpJobs J) {
+    dwp_body<H, FUSED>(J, (int)blockIdx.x, (int)gridDim.x, g_dyn_lds);
 }
 // Elementwise update from an (all-reduced) gradient, data-parallel path.  Pad entries have
 // G = delta = W = 0 and stay 0.  kernUpdatedelta + kernAccSum, DevFunc.cu:490-507,427-443.
@@ -1088,6 +1081,56 @@ __global__ __launch_bounds__(256) void k_loss_grad(const float *__restrict__ eT,
     for (int q = 0; q < 4; q++) {
         const int el = tid + 256 * q, bl = el >> 5, dl = el & 31;
         dEdX[(size_t)(b0 + bl) * Dp + d0 + dl] = tileT[bl][dl];
+    }
+}
+
+// MLflag != 1 needs no statistic over the minibatch, so phases A and B collapse into one
+// elementwise pass: slab sum + bias -> error -> beta-norm gradient (same expressions and order as
+// k_loss_err / k_loss_grad), written as dEdXt and, through an LDS transpose, dEdX.
+__global__ __launch_bounds__(256) void k_loss_norm(const float *__restrict__ slab, int S, const float *__restrict__ bias,
+                                                   const float *__restrict__ targ, int B, int D, int Dp, int Bp,
+                                                   float beta, float inv_n, float *__restrict__ outT,
+                                                   float *__restrict__ eT, float *__restrict__ dEdXt,
+                                                   float *__restrict__ dEdX, int b_tiles,
+                                                   const int *__restrict__ first, int toff) {
+    __shared__ float tt[32][33];
+    __shared__ float tg[32][33];
+    const int dt = blockIdx.x / b_tiles, bt = blockIdx.x % b_tiles;
+    const int d0 = dt * 32, b0 = bt * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int b = b0 + ty + 8 * q, d = d0 + tx;
+        tt[ty + 8 * q][tx] = (b < B && d < D) ? targ[(size_t)(first ? first[b] + toff : b) * D + d] : 0.0f;
+    }
+    __syncthreads();
+    const size_t slab_stride = (size_t)Dp * Bp;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int dl = ty + 8 * q, d = d0 + dl, b = b0 + tx;
+        const size_t o = (size_t)d * Bp + b;
+        float x = slab_sum(slab, o, slab_stride, S);
+        x = x + bias[d];
+        float e = 0.0f, g = 0.0f;
+        if (b < B && d < D) {
+            e = x - tt[tx][dl];  // kernerror
+            if (e > 0) g = beta * powf(e, beta - 1);  // kernSubClean2
+            else if (e == 0) g = 0;
+            else g = -beta * powf(-e, beta - 1);
+            g = g * inv_n;  // kernVecMulNum
+        } else {
+            x = 0.0f;
+        }
+        outT[o] = x;
+        eT[o] = e;
+        dEdXt[o] = g;
+        tg[tx][dl] = g;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int bl = ty + 8 * q;
+        dEdX[(size_t)(b0 + bl) * Dp + d0 + tx] = tg[bl][tx];
     }
 }
 

@@ -16,6 +16,7 @@ if len(sys.argv) > 1:
 ref = None
 for rnd in range(2):
     for cfg in configs:
+        for k in [k for k in os.environ if k.startswith("MLGGD_")]: del os.environ[k]
         os.environ.update(cfg)
         eng = pkg.BPGpu(1, 0, ls, B, 0.1, 0.9, 1e-5, ws, bs, 2.0, 0)
         eng.load_chunk(inp, targ)
