@@ -125,13 +125,14 @@ struct mlggd_engine {
     int chunk_frames = 0;
     // indexed chunk: raw frame streams + first frame of every sample row
     float *raw_feat = nullptr, *raw_targ = nullptr, *in_bunch = nullptr;
+    float *in_bunch_buf[2] = {nullptr, nullptr};  // in_bunch alternates between them when bunches are staged ahead
     int *first_frame = nullptr;
     size_t raw_cap = 0, first_cap = 0;
     bool indexed = false;
     int fdim = 0, toff = 0, raw_frames = 0;
     unsigned step_counter = 0;
     // launch-plan knobs (defaults chosen from measurements; env overrides for A/B runs)
-    int fwd_nw = 8, dx_nw = 8, dw_tile = 1, dw_persist = 1, dwp_per_cu = 2, dw_merge = 1, loss_fuse = 1, tile_map = 0;  // dw_tile 0 = auto
+    int fwd_nw = 8, dx_nw = 8, dw_tile = 1, dw_persist = 1, dwp_per_cu = 2, dw_merge = 1, loss_fuse = 1, tile_map = 0, stage_ahead = 1;  // dw_tile 0 = auto
 
     // data parallel
     int world = 1, rank = 0;
@@ -308,11 +309,30 @@ static Bunch bunch_at(mlggd_engine *e, int sample) {
 // row-major [frames][K0] view of the bunch for the layer-1 dW operand / dropout
 static const float *bunch_rows(mlggd_engine *e, const Bunch &b) { return b.first ? e->in_bunch : b.in; }
 
+static StageArgs stage_args(mlggd_engine *e, const Bunch &bn, int frames, float *rows_out) {
+    StageArgs a;
+    a.in = bn.in;
+    a.ld = e->K0;
+    a.B = frames;
+    a.K = e->K0;
+    a.inT = e->Yt[0];
+    a.Bp = e->Bp;
+    a.b_tiles = e->Bp / 32;
+    a.first = bn.first;
+    a.fdim = e->fdim;
+    a.rows_out = bn.first ? rows_out : nullptr;
+    return a;
+}
+static int stage_blocks(const mlggd_engine *e) { return (e->lsp[0] / 32) * (e->Bp / 32); }
+// the other half of the in_bunch double buffer (target of a bunch staged one step ahead)
+static float *in_bunch_other(mlggd_engine *e) {
+    return e->in_bunch == e->in_bunch_buf[0] ? e->in_bunch_buf[1] : e->in_bunch_buf[0];
+}
+
 static int run_transpose(mlggd_engine *e, const Bunch &bn, int frames) {
     ProfScope ps(e, KC_TRANSPOSE, 0);
-    const int b_tiles = e->Bp / 32, k_tiles = e->lsp[0] / 32;
-    hipLaunchKernelGGL(k_transpose_in, dim3(k_tiles * b_tiles), dim3(256), 0, e->stream, bn.in, e->K0, frames, e->K0,
-                       e->Yt[0], e->Bp, b_tiles, bn.first, e->fdim, bn.first ? e->in_bunch : (float *)nullptr);
+    hipLaunchKernelGGL(k_transpose_in, dim3(stage_blocks(e)), dim3(256), 0, e->stream,
+                       stage_args(e, bn, frames, e->in_bunch));
     return launch_check("k_transpose_in");
 }
 
@@ -328,8 +348,14 @@ static int run_dropout(mlggd_engine *e, int layer, const float *chunk_rows) {
     return launch_check("k_dropout");
 }
 
-static int run_forward(mlggd_engine *e, const Bunch &bn, int frames, bool training) {
-    CHK(run_transpose(e, bn, frames));
+// prestaged: Yt[0] (and, for frame-stream chunks, the other in_bunch buffer) already hold this
+// bunch -- the previous training step staged it alongside its loss kernel
+static int run_forward(mlggd_engine *e, const Bunch &bn, int frames, bool training, bool prestaged = false) {
+    if (prestaged) {
+        if (bn.first) e->in_bunch = in_bunch_other(e);
+    } else {
+        CHK(run_transpose(e, bn, frames));
+    }
     const float *in_rows = bunch_rows(e, bn);
     const int b_tiles = e->Bp / 32;
     const bool drop = training && e->cfg.dropoutflag == 1;
@@ -465,8 +491,9 @@ static BiasJobs make_bias_jobs(mlggd_engine *e) {
 
 // One SGD step on `frames` (= bunchsize) resident frames: BP_GPU::train_bunch_single,
 // BP_GPU.cu:308-440.
-static int run_step(mlggd_engine *e, const Bunch &bn) {
-    const float *in_rows = bunch_rows(e, bn);
+// next != nullptr: also stage that bunch's input for the following step (its blocks ride along
+// with the loss kernel; see k_loss_norm).  prestaged: this bunch was staged that way.
+static int run_step(mlggd_engine *e, const Bunch &bn, bool prestaged = false, const Bunch *next = nullptr) {
     const float *targ_rows = bn.targ;
     const int L = e->L, B = e->B, Bp = e->Bp, b_tiles = Bp / 32;
     const bool dp = e->comm != nullptr;  // a 1-rank communicator still takes the exchange path (tests)
@@ -475,19 +502,36 @@ static int run_step(mlggd_engine *e, const Bunch &bn) {
     const float inv_n = 1.0f / n_global;  // DevVecMulNum(..., 1.0f/n_frames, ...), BP_GPU.cu:409,423
     const int ML = e->cfg.MLflag;
 
-    CHK(run_forward(e, bn, B, true));
+    CHK(run_forward(e, bn, B, true, prestaged));
+    const float *in_rows = bunch_rows(e, bn);  // after run_forward: it may have switched in_bunch
+    // input of the next step: Yt[0] is free from here on (forward_1 has been enqueued); frame-stream
+    // rows go to the OTHER in_bunch buffer because this step's dW(1) still reads the current one
+    StageArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    int n_stage = 0;
+    if (next) {
+        sa = stage_args(e, *next, B, in_bunch_other(e));
+        n_stage = stage_blocks(e);
+    }
     {
         ProfScope ps(e, KC_LOSS, 0);
         const size_t lds = (size_t)(32 * (Bp + 1) + 32) * sizeof(float);
+        const int n_loss = (e->Dp / 32) * b_tiles;
         if (ML != 1 && e->loss_fuse) {
-            hipLaunchKernelGGL(k_loss_norm, dim3((e->Dp / 32) * b_tiles), dim3(256), 0, e->stream, e->slab, e->S_out,
-                               e->bias[L - 1], targ_rows, B, e->D, e->Dp, Bp, e->cfg.shapefactor, inv_n, e->outT, e->eT,
-                               e->dEdXt[L - 1], e->dEdX[L - 1], b_tiles, bn.first, e->toff);
+            LossNormArgs la;
+            la.slab = e->slab; la.S = e->S_out; la.bias = e->bias[L - 1]; la.targ = targ_rows;
+            la.B = B; la.D = e->D; la.Dp = e->Dp; la.Bp = Bp; la.beta = e->cfg.shapefactor; la.inv_n = inv_n;
+            la.outT = e->outT; la.eT = e->eT; la.dEdXt = e->dEdXt[L - 1]; la.dEdX = e->dEdX[L - 1];
+            la.b_tiles = b_tiles; la.first = bn.first; la.toff = e->toff;
+            hipLaunchKernelGGL(k_loss_norm, dim3(n_loss + n_stage), dim3(256), 0, e->stream, la, n_loss, sa);
             CHK(launch_check("k_loss_norm"));
         } else {
-            hipLaunchKernelGGL(k_loss_err, dim3((e->Dp / 32) * b_tiles), dim3(256), 0, e->stream, e->slab, e->S_out,
-                               e->bias[L - 1], targ_rows, B, e->D, e->Dp, Bp, e->cfg.shapefactor, ML == 1 ? 1 : 0,
-                               e->outT, e->eT, e->pT, b_tiles, bn.first, e->toff);
+            LossErrArgs la;
+            la.slab = e->slab; la.S = e->S_out; la.bias = e->bias[L - 1]; la.targ = targ_rows;
+            la.B = B; la.D = e->D; la.Dp = e->Dp; la.Bp = Bp; la.beta = e->cfg.shapefactor; la.want_pow = ML == 1 ? 1 : 0;
+            la.outT = e->outT; la.eT = e->eT; la.pT = e->pT;
+            la.b_tiles = b_tiles; la.first = bn.first; la.toff = e->toff;
+            hipLaunchKernelGGL(k_loss_err, dim3(n_loss + n_stage), dim3(256), 0, e->stream, la, n_loss, sa);
             CHK(launch_check("k_loss_err"));
             const float *colsum_in = nullptr;
             if (dp && ML == 1) {
@@ -631,6 +675,7 @@ int mlggd_create(const mlggd_config *cfg, const float *const *weights, const flo
     if (const char *v = getenv("MLGGD_DW_MERGE")) e->dw_merge = atoi(v);
     if (const char *v = getenv("MLGGD_LOSS_FUSE")) e->loss_fuse = atoi(v);
     if (const char *v = getenv("MLGGD_TILE_MAP")) e->tile_map = atoi(v);
+    if (const char *v = getenv("MLGGD_STAGE_AHEAD")) e->stage_ahead = atoi(v);
     *out = e;  // so the caller can destroy on failure
 
     HIPCHK(hipSetDevice(e->device));
@@ -643,7 +688,9 @@ int mlggd_create(const mlggd_config *cfg, const float *const *weights, const flo
 
     const int L = e->L, Bp = e->Bp;
     CHK(dev_alloc(e, &e->Yt[0], (size_t)e->lsp[0] * Bp));
-    CHK(dev_alloc(e, &e->in_bunch, (size_t)(Bp + 1) * e->lsp[0]));
+    CHK(dev_alloc(e, &e->in_bunch_buf[0], (size_t)(Bp + 1) * e->lsp[0]));
+    CHK(dev_alloc(e, &e->in_bunch_buf[1], (size_t)(Bp + 1) * e->lsp[0]));
+    e->in_bunch = e->in_bunch_buf[0];
     for (int l = 1; l < L; l++) {
         const size_t wsz = (size_t)e->lsp[l - 1] * e->lsp[l];
         CHK(dev_alloc(e, &e->W[l], wsz));
@@ -882,8 +929,13 @@ int mlggd_train_resident(mlggd_handle e, int first_frame, int n_frames, int *bun
     int trained = 0;
     HIPCHK(hipEventRecord(e->ev_t0, e->stream));
     // bunch loop of BP_GPU::train, BP_GPU.cu:170-184: full bunches only
+    bool prestaged = false;
     for (int i = 0; i + e->B <= n_frames; i += e->B) {
-        CHK(run_step(e, bunch_at(e, first_frame + i)));
+        const bool has_next = e->stage_ahead && i + 2 * e->B <= n_frames;
+        Bunch next;
+        if (has_next) next = bunch_at(e, first_frame + i + e->B);
+        CHK(run_step(e, bunch_at(e, first_frame + i), prestaged, has_next ? &next : nullptr));
+        prestaged = has_next;
         trained++;
     }
     HIPCHK(hipEventRecord(e->ev_t1, e->stream));

@@ -889,12 +889,22 @@ __global__ __launch_bounds__(256) void k_bias_apply(BiasJobs jobs, float nf, flo
 //                      nothing has to be expanded on the host).  The gathered rows are also
 //                      written row-major to rows_out[b][K] for the layer-1 dW operand.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_transpose_in(const float *__restrict__ in, int ld, int B, int K,
-                                                      float *__restrict__ inT, int Bp, int b_tiles,
-                                                      const int *__restrict__ first, int fdim,
-                                                      float *__restrict__ rows_out) {
+struct StageArgs {
+    const float *in;
+    int ld, B, K;
+    float *inT;
+    int Bp, b_tiles;
+    const int *first;
+    int fdim;
+    float *rows_out;
+};
+__device__ __forceinline__ void transpose_in_body(const StageArgs &A, const int bid) {
+    const float *__restrict__ in = A.in;
+    float *__restrict__ inT = A.inT, *__restrict__ rows_out = A.rows_out;
+    const int *__restrict__ first = A.first;
+    const int ld = A.ld, B = A.B, K = A.K, Bp = A.Bp, b_tiles = A.b_tiles, fdim = A.fdim;
     __shared__ float t[32][33];
-    const int kt = blockIdx.x / b_tiles, bt = blockIdx.x % b_tiles;
+    const int kt = bid / b_tiles, bt = bid % b_tiles;
     const int k0 = kt * 32, b0 = bt * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
 #pragma unroll
@@ -915,6 +925,7 @@ __global__ __launch_bounds__(256) void k_transpose_in(const float *__restrict__ 
         inT[(size_t)k * Bp + b0 + tx] = t[tx][ty + 8 * q];
     }
 }
+__global__ __launch_bounds__(256) void k_transpose_in(StageArgs A) { transpose_in_body(A, (int)blockIdx.x); }
 
 // Sum of the S split-K slabs of one output element, slabs added in order s = 0..S-1.  All
 // loads are issued before the first add (one memory round trip instead of S).
@@ -937,15 +948,28 @@ __device__ __forceinline__ float slab_sum(const float *__restrict__ slab, size_t
 // BP_GPU.cu:413-415).  Writes outT, eT, pT, all [Dp][Bp] with zeros in the pads.  targ is the
 // caller's row-major [B][D]; it is read in 128-byte row segments and transposed through LDS.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_loss_err(const float *__restrict__ slab, int S, const float *__restrict__ bias,
-                                                  const float *__restrict__ targ, int B, int D, int Dp, int Bp,
-                                                  float beta, int want_pow, float *__restrict__ outT,
-                                                  float *__restrict__ eT, float *__restrict__ pT, int b_tiles,
-                                                  const int *__restrict__ first, int toff) {
+struct LossErrArgs {
+    const float *slab;
+    int S;
+    const float *bias, *targ;
+    int B, D, Dp, Bp;
+    float beta;
+    int want_pow;
+    float *outT, *eT, *pT;
+    int b_tiles;
+    const int *first;
+    int toff;
+};
+__device__ __forceinline__ void loss_err_body(const LossErrArgs &A, const int bid) {
+    const float *__restrict__ slab = A.slab, *__restrict__ bias = A.bias, *__restrict__ targ = A.targ;
+    float *__restrict__ outT = A.outT, *__restrict__ eT = A.eT, *__restrict__ pT = A.pT;
+    const int *__restrict__ first = A.first;
+    const int S = A.S, B = A.B, D = A.D, Dp = A.Dp, Bp = A.Bp, want_pow = A.want_pow, b_tiles = A.b_tiles, toff = A.toff;
+    const float beta = A.beta;
     // first != nullptr: targ is the raw target frame stream and sample b's target is frame
     // first[b] + toff of it (Interface.cc:822-825); otherwise row b of the caller's [B][D] matrix
     __shared__ float tt[32][33];
-    const int dt = blockIdx.x / b_tiles, bt = blockIdx.x % b_tiles;
+    const int dt = bid / b_tiles, bt = bid % b_tiles;
     const int d0 = dt * 32, b0 = bt * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
 #pragma unroll
@@ -972,6 +996,13 @@ __global__ __launch_bounds__(256) void k_loss_err(const float *__restrict__ slab
         eT[o] = e;
         pT[o] = p;
     }
+}
+// The blocks past n_loss stage the NEXT minibatch's input (it depends on nothing in this step and
+// Yt[0] is free once forward_1 has run): the loss kernel occupies 36 of 256 CUs, so the staging
+// blocks ride along on the idle ones instead of costing a launch of their own.
+__global__ __launch_bounds__(256) void k_loss_err(LossErrArgs A, int n_loss, StageArgs G) {
+    if ((int)blockIdx.x < n_loss) loss_err_body(A, (int)blockIdx.x);
+    else transpose_in_body(G, (int)blockIdx.x - n_loss);
 }
 
 // Per-dimension sum over the minibatch of |e|^beta in the reference's order (kernSumcol,
@@ -1087,15 +1118,26 @@ __global__ __launch_bounds__(256) void k_loss_grad(const float *__restrict__ eT,
 // MLflag != 1 needs no statistic over the minibatch, so phases A and B collapse into one
 // elementwise pass: slab sum + bias -> error -> beta-norm gradient (same expressions and order as
 // k_loss_err / k_loss_grad), written as dEdXt and, through an LDS transpose, dEdX.
-__global__ __launch_bounds__(256) void k_loss_norm(const float *__restrict__ slab, int S, const float *__restrict__ bias,
-                                                   const float *__restrict__ targ, int B, int D, int Dp, int Bp,
-                                                   float beta, float inv_n, float *__restrict__ outT,
-                                                   float *__restrict__ eT, float *__restrict__ dEdXt,
-                                                   float *__restrict__ dEdX, int b_tiles,
-                                                   const int *__restrict__ first, int toff) {
+struct LossNormArgs {
+    const float *slab;
+    int S;
+    const float *bias, *targ;
+    int B, D, Dp, Bp;
+    float beta, inv_n;
+    float *outT, *eT, *dEdXt, *dEdX;
+    int b_tiles;
+    const int *first;
+    int toff;
+};
+__device__ __forceinline__ void loss_norm_body(const LossNormArgs &A, const int bid) {
+    const float *__restrict__ slab = A.slab, *__restrict__ bias = A.bias, *__restrict__ targ = A.targ;
+    float *__restrict__ outT = A.outT, *__restrict__ eT = A.eT, *__restrict__ dEdXt = A.dEdXt, *__restrict__ dEdX = A.dEdX;
+    const int *__restrict__ first = A.first;
+    const int S = A.S, B = A.B, D = A.D, Dp = A.Dp, Bp = A.Bp, b_tiles = A.b_tiles, toff = A.toff;
+    const float beta = A.beta, inv_n = A.inv_n;
     __shared__ float tt[32][33];
     __shared__ float tg[32][33];
-    const int dt = blockIdx.x / b_tiles, bt = blockIdx.x % b_tiles;
+    const int dt = bid / b_tiles, bt = bid % b_tiles;
     const int d0 = dt * 32, b0 = bt * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
 #pragma unroll
@@ -1132,6 +1174,10 @@ __global__ __launch_bounds__(256) void k_loss_norm(const float *__restrict__ sla
         const int bl = ty + 8 * q;
         dEdX[(size_t)(b0 + bl) * Dp + d0 + tx] = tg[bl][tx];
     }
+}
+__global__ __launch_bounds__(256) void k_loss_norm(LossNormArgs A, int n_loss, StageArgs G) {
+    if ((int)blockIdx.x < n_loss) loss_norm_body(A, (int)blockIdx.x);
+    else transpose_in_body(G, (int)blockIdx.x - n_loss);
 }
 
 // Forward-only output (cv_bunch_single, BP_GPU.cu:442-512): out[b][d] = bias + sum_s slab,
