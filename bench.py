@@ -128,7 +128,10 @@ def main():
             ach = fl / (us * 1e-6) / 1e12
             traffic = None
             pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(pmc):  # HBM bytes per launch from rocprofv3 --pmc runs (profiles/README.md)
+            # HBM bytes per launch from rocprofv3 --pmc runs (profiles/README.md); they were collected on
+            # the single-GPU plan (one launch for all layers, default shape) and only describe that one
+            default_shape = (B == 128 and args.hidden == 2048 and args.nhid == 3)
+            if os.path.exists(pmc) and world == 1 and nl == 1 and default_shape:
                 try:
                     traffic = json.load(open(pmc)).get("k_dw", {}).get("hbm_bytes_per_launch")
                 except Exception:
