@@ -69,6 +69,27 @@ def test_intermediates_one_step_odd_shapes(pkg, pyoracle, synth, ml, beta):
     eng.close()
 
 
+@pytest.mark.parametrize("B", [64, 96, 200, 256, 500, 512])
+def test_every_bunch_size_variant_of_the_dw_kernel(pkg, pyoracle, synth, B):
+    # Bp = 64, 128, 256, 512 take the persistent multi-layer dW kernel (H = 1, 2, 4, 8 units per tile),
+    # Bp = 96 the per-layer fallback; 7 layers = 6 jobs in one launch, tile counts that are not
+    # multiples of anything
+    ls = [70, 130, 64, 33, 96, 40, 21]
+    eng, ora = make_pair(pkg, pyoracle, synth, ls, B, 1, 1.2, seed=11)
+    inp, targ = synth.make_frames(2 * B, 10, 7, seed=12)
+    targ = np.ascontiguousarray(np.tile(targ, (1, 3))[:, :21])
+    assert eng.train(inp, targ) == 2
+    assert ora.train(inp, targ) == 2
+    we, be = eng.returnWeights()
+    wo, bo = ora.get_weights()
+    for l in range(len(we)):
+        assert relmax(we[l], wo[l]) < 2e-5, l
+        assert relmax(be[l], bo[l]) < 2e-5, l
+        assert relmax(eng.debug_tensor("delta_w", l + 1), ora.tensor("delta_w", l + 1)) < 2e-4, l
+        assert relmax(eng.debug_tensor("delta_b", l + 1), ora.tensor("delta_b", l + 1)) < 2e-4, l
+    eng.close()
+
+
 @pytest.mark.parametrize("ml,beta", [(0, 2.0), (1, 1.2)])
 def test_baseline_net_two_steps(pkg, pyoracle, synth, ml, beta):
     """BASELINE.json configs 2/3: 2827-2048x3-257, 128-frame minibatch."""
