@@ -121,6 +121,50 @@ def test_frame_stream_chunks_equal_expanded_chunks_bitwise(pkg, synth, ml, beta)
     b.close()
 
 
+@pytest.mark.parametrize("frames_mode", [False, True])
+def test_launch_plan_knobs_do_not_change_a_bit(pkg, synth, monkeypatch, frames_mode):
+    """The launch-plan optimisations (next minibatch staged alongside the loss kernel, one dW launch
+    for all layers, fused MMSE loss kernel) reorder launches, not arithmetic: weights after 5 steps are
+    bit-identical with each of them switched off, for expanded and for frame-stream chunks, and when
+    the chunk is trained in two calls (the staged-ahead bunch is then dropped at the call boundary)."""
+    dim, ctx, B, toff = 40, 5, 64, 2
+    ls = [dim * ctx, 96, 70, dim]
+    rng = np.random.default_rng(5)
+    nfr = 600
+    feat = rng.standard_normal((nfr, dim), dtype=np.float32)
+    targ = (0.5 * feat + 0.5 * rng.standard_normal((nfr, dim), dtype=np.float32)).astype(np.float32)
+    first = rng.permutation(nfr - ctx + 1)[:5 * B + 9].astype(np.int32)
+    idx = first[:, None] + np.arange(ctx)[None, :]
+    inp = np.ascontiguousarray(feat[idx].reshape(len(first), ctx * dim))
+    tg = np.ascontiguousarray(targ[first + toff])
+    ws, bs = synth.make_weights(ls, seed=6)
+
+    def run(env, split=False):
+        for k in ("MLGGD_STAGE_AHEAD", "MLGGD_DW_MERGE", "MLGGD_LOSS_FUSE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = pkg.BPGpu(1, 0, ls, B, *HP, ws, bs, 2.0, 0)
+        if frames_mode:
+            eng.load_frames(feat, targ, first, ctx, toff)
+        else:
+            eng.load_chunk(inp, tg)
+        if split:
+            assert eng.train_resident(0, 2 * B) == 2
+            assert eng.train_resident(2 * B, 3 * B + 9) == 3
+        else:
+            assert eng.train_resident(0, len(first)) == 5
+        w, b = eng.returnWeights()
+        eng.close()
+        return w + b
+
+    ref = run({})
+    for env, split in (({"MLGGD_STAGE_AHEAD": "0"}, False), ({"MLGGD_DW_MERGE": "0"}, False),
+                       ({"MLGGD_LOSS_FUSE": "0"}, False), ({}, True)):
+        for x, y in zip(ref, run(env, split)):
+            assert np.array_equal(x, y), (env, split)
+
+
 def test_linearity_of_forward_at_full_size(pkg, synth):
     """Size-independent property at BASELINE size: with one linear layer the network output is
     linear in the input; f(a x1 + b x2) = a f(x1) + b f(x2) - (a+b-1) bias."""
