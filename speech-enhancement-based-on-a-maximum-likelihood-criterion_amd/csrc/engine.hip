@@ -444,15 +444,16 @@ static DwpJobs dwp_jobs(mlggd_engine *e, int lhi, int llo, const float *in_rows,
     return J;
 }
 template <int H>
-static int launch_dwp_t(mlggd_engine *e, const DwpJobs &J, bool fused, hipStream_t st) {
+static int launch_dwp_t(mlggd_engine *e, const DwpJobs &J, bool fused, hipStream_t st, int stamp_layer) {
     const size_t lds = dwp_lds_floats() * sizeof(float);
     const int grid = dwp_grid(e, J.total);
+    long long *stamps = stamps_for(e, KC_DW, stamp_layer, grid);
     if (fused) {
         CHK(ensure_lds(k_dwp<H, true>, lds));
-        hipLaunchKernelGGL((k_dwp<H, true>), dim3(grid), dim3(256), lds, st, J);
+        hipLaunchKernelGGL((k_dwp<H, true>), dim3(grid), dim3(256), lds, st, J, stamps);
     } else {
         CHK(ensure_lds(k_dwp<H, false>, lds));
-        hipLaunchKernelGGL((k_dwp<H, false>), dim3(grid), dim3(256), lds, st, J);
+        hipLaunchKernelGGL((k_dwp<H, false>), dim3(grid), dim3(256), lds, st, J, stamps);
     }
     return launch_check("k_dwp");
 }
@@ -460,12 +461,12 @@ static bool dwp_usable(const mlggd_engine *e) {
     const int Hh = e->Bp / 64;
     return e->dw_persist && e->Bp % 64 == 0 && (Hh == 1 || Hh == 2 || Hh == 4 || Hh == 8);
 }
-static int launch_dwp(mlggd_engine *e, const DwpJobs &J, bool fused, hipStream_t st) {
+static int launch_dwp(mlggd_engine *e, const DwpJobs &J, bool fused, hipStream_t st, int stamp_layer) {
     switch (e->Bp / 64) {
-    case 1: return launch_dwp_t<1>(e, J, fused, st);
-    case 2: return launch_dwp_t<2>(e, J, fused, st);
-    case 4: return launch_dwp_t<4>(e, J, fused, st);
-    default: return launch_dwp_t<8>(e, J, fused, st);
+    case 1: return launch_dwp_t<1>(e, J, fused, st, stamp_layer);
+    case 2: return launch_dwp_t<2>(e, J, fused, st, stamp_layer);
+    case 4: return launch_dwp_t<4>(e, J, fused, st, stamp_layer);
+    default: return launch_dwp_t<8>(e, J, fused, st, stamp_layer);
     }
 }
 
@@ -579,7 +580,7 @@ static int run_step(mlggd_engine *e, const Bunch &bn, bool prestaged = false, co
             const bool big = e->dw_tile == 0 ? tiles128 >= 192 : e->dw_tile == 2;
             ProfScope ps(e, KC_DW, l, dws);
             if (dwp_usable(e))
-                CHK(launch_dwp(e, dwp_jobs(e, l, l, in_rows, nf), !dp, dws));
+                CHK(launch_dwp(e, dwp_jobs(e, l, l, in_rows, nf), !dp, dws, l));
             else if (big)
                 CHK(launch_dw<2>(e, l, in_rows, !dp, nf, dws));
             else
@@ -594,7 +595,7 @@ static int run_step(mlggd_engine *e, const Bunch &bn, bool prestaged = false, co
     }
     if (merged) {
         ProfScope ps(e, KC_DW, 1, dws);
-        CHK(launch_dwp(e, dwp_jobs(e, L - 1, 1, in_rows, nf), true, dws));
+        CHK(launch_dwp(e, dwp_jobs(e, L - 1, 1, in_rows, nf), true, dws, 1));
     }
     if (dp) {
         // bias gradients were written by the dw kernels; ev_grad[1] is the last of them

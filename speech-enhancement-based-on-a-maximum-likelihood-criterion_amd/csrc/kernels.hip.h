@@ -66,6 +66,14 @@ __device__ __forceinline__ void stamp(long long *stamps, int slot, int bid = -1)
         stamps[(size_t)(bid < 0 ? (int)blockIdx.x : bid) * 8 + slot] = (long long)__builtin_amdgcn_s_memrealtime();
     }
 }
+// shader-clock counter next to the wall-clock stamp: (slot+1 - slot'+1) / (slot - slot') * 100 MHz is
+// the clock the workgroup actually ran at
+__device__ __forceinline__ void stamp_clk(long long *stamps, int slot, int bid) {
+    if (stamps != nullptr && threadIdx.x == 0) {
+        stamps[(size_t)bid * 8 + slot] = (long long)__builtin_amdgcn_s_memrealtime();
+        stamps[(size_t)bid * 8 + slot + 1] = (long long)__builtin_amdgcn_s_memtime();
+    }
+}
 // wave index as a provably wave-uniform value (scalar branches, exact s_waitcnt counts)
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
@@ -105,6 +113,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &A, const int bid, float 
     // reduction buffer red[NW][1024] aliases the same storage after the main loop
     float(*tileT)[33] = reinterpret_cast<float(*)[33]>(smem + NW * 2048);
     stamp(stamps, 0, bid);
+    stamp_clk(stamps, 4, bid);
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
     const int i = lane & 31, h = lane >> 5;
     int id = bid, s = 0;
@@ -231,6 +240,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &A, const int bid, float 
         }
     }
     stamp(stamps, 3, bid);
+    stamp_clk(stamps, 6, bid);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -639,8 +649,10 @@ __device__ __forceinline__ DwpTile dwp_locate(const DwpJobs &J, const int t, con
 }
 
 // bid / nblocks: this workgroup's index and the number of workgroups walking the tiles
-template <int H, bool FUSED>
-__device__ __forceinline__ void dwp_body(const DwpJobs &J, const int bid, const int nblocks, float *lds) {
+template <int H, bool FUSED, bool interleave = true>
+__device__ __forceinline__ void dwp_body(const DwpJobs &J, const int bid, const int nblocks, float *lds,
+                                         long long *stamps) {
+    stamp_clk(stamps, 0, bid);  // diagnostic (nullptr in every normal launch): wall + shader clock at start / end
     const int B = J.job[0].B;
     const float nf = J.job[0].nf, mom = J.job[0].mom, lr = J.job[0].lr, wc = J.job[0].wc;
     constexpr int OOB = 0x7FFFFF00;  // byte offset beyond every descriptor: load -> 0, store dropped
@@ -761,6 +773,19 @@ __device__ __forceinline__ void dwp_body(const DwpJobs &J, const int bid, const 
         }                                                                                       \
         _Pragma("unroll") for (int r = 0; r < 16; r++) acc[r] = 0.0f;                           \
     }
+    // Issue order inside a unit: the 8 + PPU vector loads are spread between the MFMAs (one load per
+    // two MFMAs) instead of ahead of them -- after a barrier all waves of the CU issue their loads at
+    // once and each waited ~0.7 us in the memory pipeline's queue before its first MFMA.
+#define DWP_INTERLEAVE()                                                                        \
+    {                                                                                           \
+        if (interleave) {                                                                       \
+            _Pragma("unroll") for (int g = 0; g < 8 + (FUSED ? PPU : 0); g++) {                 \
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                              \
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                              \
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                              \
+            }                                                                                   \
+        }                                                                                       \
+    }
     // one tile whose first unit sits in LDS buffer BASE: PWC/PDC = this tile's W/delta registers,
     // PWN/PDN = the next tile's (an invalid next tile has empty descriptors: its loads cost nothing)
 #define DWP_TILE(PWC, PDC, PWN, PDN, BASE)                                                      \
@@ -769,11 +794,12 @@ __device__ __forceinline__ void dwp_body(const DwpJobs &J, const int bid, const 
         const DwpTile tn = dwp_locate(J, tnext, Bp);                                            \
         _Pragma("unroll") for (int hh = 0; hh < H; hh++) {                                      \
             const int buf = ((BASE) + hh) & 1;                                                  \
+            DWP_BIAS(buf, hh)                                                                   \
             if (hh + 1 < H) DWP_LOAD_UNIT(tc, hh + 1)                                           \
             else DWP_LOAD_UNIT(tn, 0)                                                           \
             DWP_PREFETCH(PWN, PDN, tn, hh)                                                      \
-            DWP_BIAS(buf, hh)                                                                   \
             DWP_MFMA(buf)                                                                       \
+            DWP_INTERLEAVE()                                                                    \
             if (hh == H - 1) DWP_EPILOGUE(buf, PWC, PDC)                                        \
             DWP_WRITE_UNIT(buf ^ 1)                                                             \
             __syncthreads();                                                                    \
@@ -793,6 +819,8 @@ __device__ __forceinline__ void dwp_body(const DwpJobs &J, const int bid, const 
         DWP_TILE(pw0, pd0, pw1, pd1, 0)
         DWP_TILE(pw1, pd1, pw0, pd0, H & 1)
     }
+    stamp_clk(stamps, 2, bid);
+    if (stamps != nullptr && threadIdx.x == 0) stamps[(size_t)bid * 8 + 4] = (t - bid) / nblocks + 1;  // tiles walked
 #undef DWP_LOAD_UNIT
 #undef DWP_WRITE_UNIT
 #undef DWP_OFF
@@ -801,6 +829,7 @@ __device__ __forceinline__ void dwp_body(const DwpJobs &J, const int bid, const 
 #undef DWP_BIAS
 #undef DWP_EPILOGUE
 #undef DWP_TILE
+#undef DWP_INTERLEAVE
 }
 
 // ---------------------------------------------------------------------------------------
@@ -822,8 +851,8 @@ __global__ __launch_bounds__(64 * NW) void k_dx(DxArgs A, long long *stamps) {
     dx_body<NW>(A, (int)blockIdx.x, g_dyn_lds, stamps);
 }
 template <int H, bool FUSED>
-__global__ __launch_bounds__(256) void k_dwp(DwpJobs J) {
-    dwp_body<H, FUSED>(J, (int)blockIdx.x, (int)gridDim.x, g_dyn_lds);
+__global__ __launch_bounds__(256) void k_dwp(DwpJobs J, long long *stamps) {
+    dwp_body<H, FUSED>(J, (int)blockIdx.x, (int)gridDim.x, g_dyn_lds, stamps);
 }
 // Elementwise update from an (all-reduced) gradient, data-parallel path.  Pad entries have
 // G = delta = W = 0 and stay 0.  kernUpdatedelta + kernAccSum, DevFunc.cu:490-507,427-443.
