@@ -139,9 +139,12 @@ def main():
             # which roof binds this kernel: arithmetic intensity against the machine balance
             # 157.3 TFLOP/s / 8 TB/s = 19.7 FLOP/B (at B = 128 the kernel moves 16 B per 2*B flops -> HBM)
             gbps = by / (us * 1e-6) / 1e9
-            name = "k_dwp<%d,%s> (persistent dW GEMM + fused momentum/weight-decay/bias update, %s)" % (
-                max(1, ((B + 31) // 32 * 32) // 64), "true" if world == 1 else "false",
-                "all layers in one launch" if nl == 1 else "one launch per layer")
+            gather = world > 1 and eng.dp_mode() == 2  # every rank runs the fused kernel over the gathered minibatch
+            units = max(1, ((B + 31) // 32 * 32) * (world if gather else 1) // 64)
+            name = "k_dwp<%d,%s> (persistent dW GEMM + fused momentum/weight-decay/bias update, %s%s)" % (
+                units, "true" if (world == 1 or gather) else "false",
+                "all layers in one launch" if nl == 1 else "one launch per layer",
+                ", over the %d gathered frames of all ranks" % (B * world) if gather else "")
             if fl / by < MFMA_F32_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBPS * 1e9):
                 roofline = {"bound": "hbm", "kernel": name, "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS,
                             "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": traffic}
@@ -166,7 +169,9 @@ def main():
                    % (ls[0], "x".join(str(x) for x in ls[1:]),
                       "ML-GGD loss (MLflag=1, beta=1.2)" if ml else "MMSE loss (MLflag=0, beta=2)", B),
                    "layersizes": ls, "bunchsize_per_gpu": B, "global_minibatch": B * world,
-                   "parallelism": "dp%d" % world, "flop_per_frame": fpf},
+                   "parallelism": "dp%d" % world, "flop_per_frame": fpf,
+                   "dp_exchange": {0: None, 1: "all-reduce of weight gradients (RCCL)",
+                                   2: "all-gather of the gradient factors Y, dEdX (RCCL); every rank forms the global gradient"}[eng.dp_mode()]},
         "step_roofline_frac": round(value * fpf / (world * MFMA_F32_PEAK_TFLOPS * 1e12), 4),
         "roofline": roofline,
     }

@@ -44,7 +44,7 @@ EXPORTS = [
     "mlggd_get_scalefactor", "mlggd_set_scalefactor", "mlggd_set_lrate", "mlggd_gamma",
     "mlggd_debug_tensor", "mlggd_comm_unique_id", "mlggd_comm_init", "mlggd_last_train_ms",
     "mlggd_profile_select", "mlggd_profile_stride", "mlggd_profile_read", "mlggd_profile_overhead",
-    "mlggd_kernel_work", "mlggd_dw_launches_per_step",
+    "mlggd_kernel_work", "mlggd_dw_launches_per_step", "mlggd_dp_mode", "mlggd_debug_fake_world",
     "mlggd_debug_stamp_select", "mlggd_debug_stamp_read",
     "mlggd_load_frames", "mlggd_train_frames", "mlggd_cv_all_frames", "mlggd_forward_frames",
     "mlggd_alloc_pinned", "mlggd_free_pinned",
@@ -103,6 +103,8 @@ def load():
     L.mlggd_kernel_work.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_double),
                                     C.POINTER(C.c_double)]
     L.mlggd_dw_launches_per_step.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    L.mlggd_dp_mode.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    L.mlggd_debug_fake_world.argtypes = [C.c_void_p, C.c_int]
     L.mlggd_debug_stamp_select.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     L.mlggd_debug_stamp_read.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.c_int, C.POINTER(C.c_int)]
     _ip = C.POINTER(C.c_int32)
@@ -384,6 +386,15 @@ class BPGpu:
         n = C.c_int(0)
         _check(load().mlggd_dw_launches_per_step(self._h, C.byref(n)))
         return n.value
+
+    def dp_mode(self):
+        """0 single device, 1 all-reduce of gradients, 2 all-gather of the gradient factors"""
+        n = C.c_int(0)
+        _check(load().mlggd_dp_mode(self._h, C.byref(n)))
+        return n.value
+
+    def fake_world(self, world_size):
+        _check(load().mlggd_debug_fake_world(self._h, int(world_size)))
 
     def stamp_select(self, kernel_class, layer):
         _check(load().mlggd_debug_stamp_select(self._h, kernel_class.encode(), int(layer)))

@@ -58,6 +58,7 @@ struct RcclApi {
     int (*AllReduce)(const void *, void *, size_t, int, int, RcclComm, hipStream_t) = nullptr;
     int (*CommDestroy)(RcclComm) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, RcclComm, hipStream_t) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
 };
@@ -75,11 +76,13 @@ static int rccl_load() {
     g_rccl.CommInitRank = (int (*)(RcclComm *, int, RcclUniqueId, int))dlsym(lib, "ncclCommInitRank");
     g_rccl.AllReduce =
         (int (*)(const void *, void *, size_t, int, int, RcclComm, hipStream_t))dlsym(lib, "ncclAllReduce");
+    g_rccl.AllGather = (int (*)(const void *, void *, size_t, int, RcclComm, hipStream_t))dlsym(lib, "ncclAllGather");
     g_rccl.CommDestroy = (int (*)(RcclComm))dlsym(lib, "ncclCommDestroy");
     g_rccl.GetErrorString = (const char *(*)(int))dlsym(lib, "ncclGetErrorString");
     g_rccl.GroupStart = (int (*)())dlsym(lib, "ncclGroupStart");
     g_rccl.GroupEnd = (int (*)())dlsym(lib, "ncclGroupEnd");
-    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy)
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.AllGather || !g_rccl.CommDestroy ||
+        !g_rccl.GroupStart || !g_rccl.GroupEnd)
         return fail(MLGGD_ERR_COMM, "librccl is missing required symbols");
     g_rccl.lib = lib;
     return MLGGD_OK;
@@ -136,6 +139,12 @@ struct mlggd_engine {
 
     // data parallel
     int world = 1, rank = 0;
+    // data-parallel exchange: 0 = all-reduce of the weight gradients, 1 = all-gather of their FACTORS (the
+    // activations Y_{l-1} and dEdX_l of every rank; each rank then forms the global-minibatch gradient itself)
+    int dp_mode = 0;
+    bool fake_world = false;  // test hook: `world` identical ranks emulated with device copies, no communicator
+    float *Yall[MLGGD_MAXLAYER] = {0}, *dEdXall[MLGGD_MAXLAYER] = {0};
+    hipEvent_t ev_ready = nullptr, ev_gathered = nullptr;
     RcclComm comm = nullptr;
     hipEvent_t ev_grad[MLGGD_MAXLAYER] = {0}, ev_red[MLGGD_MAXLAYER] = {0}, ev_bias = nullptr, ev_bias_red = nullptr;
 
@@ -461,13 +470,74 @@ static bool dwp_usable(const mlggd_engine *e) {
     const int Hh = e->Bp / 64;
     return e->dw_persist && e->Bp % 64 == 0 && (Hh == 1 || Hh == 2 || Hh == 4 || Hh == 8);
 }
-static int launch_dwp(mlggd_engine *e, const DwpJobs &J, bool fused, hipStream_t st, int stamp_layer) {
-    switch (e->Bp / 64) {
+// units: 64-frame units per tile = (frames the jobs' operands hold) / 64
+static int launch_dwp(mlggd_engine *e, const DwpJobs &J, bool fused, hipStream_t st, int stamp_layer, int units = 0) {
+    switch (units > 0 ? units : e->Bp / 64) {
     case 1: return launch_dwp_t<1>(e, J, fused, st, stamp_layer);
     case 2: return launch_dwp_t<2>(e, J, fused, st, stamp_layer);
     case 4: return launch_dwp_t<4>(e, J, fused, st, stamp_layer);
-    default: return launch_dwp_t<8>(e, J, fused, st, stamp_layer);
+    case 8: return launch_dwp_t<8>(e, J, fused, st, stamp_layer);
+    case 16: return launch_dwp_t<16>(e, J, fused, st, stamp_layer);
+    default: return fail(MLGGD_ERR_STATE, "no dW kernel for %d units per tile", units);
     }
+}
+
+// ---- data-parallel exchange by all-gather of the gradient's factors (dp_mode 1) -------------------
+// G_l = sum over ranks of Y_{l-1,r}^T dEdX_{l,r} is a product of [frames x units] matrices that are 8-16 x
+// smaller than G_l itself at 128 frames per rank (7.9 MB of factors vs 58.8 MB of gradients per rank and
+// step), so the ranks exchange the factors: every rank gathers all ranks' Y_{l-1} and dEdX_l (rank-major
+// rows = the rows of ONE minibatch of world*B frames) and runs the same fused dW + update kernel over the
+// global minibatch.  All ranks compute bit-identical updates, so no gradient, bias or weight ever crosses
+// the links, there is no separate update pass, and the result is exactly the single-device step with
+// bunchsize world*B.  The price is world x the dW MFMA work per rank.
+static bool gather_usable(const mlggd_engine *e, int world) {
+    const long frames = (long)world * e->Bp;
+    const long units = frames / 64;
+    return e->dw_persist && e->B == e->Bp && frames % 64 == 0 &&
+           (units == 1 || units == 2 || units == 4 || units == 8 || units == 16);
+}
+static int gather_alloc(mlggd_engine *e) {
+    const size_t rows = (size_t)e->world * e->Bp;
+    CHK(dev_alloc(e, &e->Yall[0], rows * e->K0));
+    for (int l = 1; l < e->L; l++) {
+        if (l != e->L - 1) CHK(dev_alloc(e, &e->Yall[l], rows * e->lsp[l]));
+        CHK(dev_alloc(e, &e->dEdXall[l], rows * e->lsp[l]));
+    }
+    HIPCHK(hipEventCreateWithFlags(&e->ev_ready, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&e->ev_gathered, hipEventDisableTiming));
+    return MLGGD_OK;
+}
+// one rank's block -> every rank's slot r of dst (on the communication stream)
+static int gather_one(mlggd_engine *e, const float *src, float *dst, size_t count) {
+    if (e->fake_world) {
+        for (int r = 0; r < e->world; r++)
+            HIPCHK(hipMemcpyAsync(dst + (size_t)r * count, src, count * sizeof(float), hipMemcpyDeviceToDevice,
+                                  e->comm_stream));
+        return MLGGD_OK;
+    }
+    NCCLCHK(g_rccl.AllGather(src, dst, count, 7 /* ncclFloat32 */, e->comm, e->comm_stream));
+    return MLGGD_OK;
+}
+// the communication stream picks up everything the main stream has produced so far
+static int gather_begin(mlggd_engine *e) {
+    HIPCHK(hipEventRecord(e->ev_ready, e->stream));
+    HIPCHK(hipStreamWaitEvent(e->comm_stream, e->ev_ready, 0));
+    if (!e->fake_world) NCCLCHK(g_rccl.GroupStart());
+    return MLGGD_OK;
+}
+static int gather_end(mlggd_engine *e) {
+    if (!e->fake_world) NCCLCHK(g_rccl.GroupEnd());
+    return MLGGD_OK;
+}
+static DwpJobs dwp_jobs_global(mlggd_engine *e, float nf) {
+    DwpJobs J = dwp_jobs(e, e->L - 1, 1, e->Yall[0], nf);
+    for (int j = 0; j < J.njobs; j++) {
+        const int l = e->L - 1 - j;
+        J.job[j].Yrow = e->Yall[l - 1];
+        J.job[j].dEdX = e->dEdXall[l];
+        J.job[j].B = e->world * e->Bp;
+    }
+    return J;
 }
 
 static BiasJobs make_bias_jobs(mlggd_engine *e) {
@@ -497,7 +567,8 @@ static BiasJobs make_bias_jobs(mlggd_engine *e) {
 static int run_step(mlggd_engine *e, const Bunch &bn, bool prestaged = false, const Bunch *next = nullptr) {
     const float *targ_rows = bn.targ;
     const int L = e->L, B = e->B, Bp = e->Bp, b_tiles = Bp / 32;
-    const bool dp = e->comm != nullptr;  // a 1-rank communicator still takes the exchange path (tests)
+    const bool dp = e->comm != nullptr || e->fake_world;  // a 1-rank communicator still takes the exchange path (tests)
+    const bool gather = dp && e->dp_mode == 1;
     const int n_global = B * e->world;
     const float nf = (float)n_global;
     const float inv_n = 1.0f / n_global;  // DevVecMulNum(..., 1.0f/n_frames, ...), BP_GPU.cu:409,423
@@ -507,6 +578,12 @@ static int run_step(mlggd_engine *e, const Bunch &bn, bool prestaged = false, co
     const float *in_rows = bunch_rows(e, bn);  // after run_forward: it may have switched in_bunch
     // input of the next step: Yt[0] is free from here on (forward_1 has been enqueued); frame-stream
     // rows go to the OTHER in_bunch buffer because this step's dW(1) still reads the current one
+    if (gather) {  // the forward factors travel while loss and dX run
+        CHK(gather_begin(e));
+        CHK(gather_one(e, in_rows, e->Yall[0], (size_t)B * e->K0));
+        for (int l = 1; l < L - 1; l++) CHK(gather_one(e, e->Y[l], e->Yall[l], (size_t)Bp * e->lsp[l]));
+        CHK(gather_end(e));
+    }
     StageArgs sa;
     memset(&sa, 0, sizeof(sa));
     int n_stage = 0;
@@ -538,7 +615,10 @@ static int run_step(mlggd_engine *e, const Bunch &bn, bool prestaged = false, co
             if (dp && ML == 1) {
                 hipLaunchKernelGGL(k_colsum, dim3(e->Dp / 32), dim3(256), lds, e->stream, e->pT, B, Bp, e->colsum);
                 CHK(launch_check("k_colsum"));
-                NCCLCHK(g_rccl.AllReduce(e->colsum, e->colsum, (size_t)e->Dp, 7, 0, e->comm, e->stream));
+                if (e->fake_world)
+                    hipLaunchKernelGGL(k_scale, dim3(1), dim3(256), 0, e->stream, e->colsum, (size_t)e->Dp, (float)e->world);
+                else
+                    NCCLCHK(g_rccl.AllReduce(e->colsum, e->colsum, (size_t)e->Dp, 7, 0, e->comm, e->stream));
                 colsum_in = e->colsum;
             }
             hipLaunchKernelGGL(k_loss_grad, dim3((e->Dp / 32) * b_tiles), dim3(256), lds, e->stream, e->eT, e->pT,
@@ -552,9 +632,16 @@ static int run_step(mlggd_engine *e, const Bunch &bn, bool prestaged = false, co
     // single GPU: every dW(l) only needs dEdX_l and Y_{l-1}, so one persistent launch walks the
     // tiles of all layers after the last dX (the data-parallel path keeps one launch per layer so
     // that the all-reduce of layer l overlaps the rest of the backward pass)
-    const bool merged = !dp && !two && e->dw_merge && dwp_usable(e);
+    const bool merged = (!dp && !two && e->dw_merge && dwp_usable(e)) || gather;
+    int pending_hi = L - 1;  // gather mode: dEdX_l for l in [l .. pending_hi] are final and not yet sent
     for (int l = L - 1; l >= 1; l--) {
         const int Kp = e->lsp[l - 1], Np = e->lsp[l];
+        if (gather && l <= 2) {  // two groups: everything down to dEdX_2 beside dX_2, dEdX_1 at the end
+            CHK(gather_begin(e));
+            for (int g = pending_hi; g >= l; g--) CHK(gather_one(e, e->dEdX[g], e->dEdXall[g], (size_t)Bp * e->lsp[g]));
+            CHK(gather_end(e));
+            pending_hi = l - 1;
+        }
         if (l != 1) {
             ProfScope ps(e, KC_DX, l);
             long long *st = stamps_for(e, KC_DX, l, (Kp / 32) * b_tiles);
@@ -586,18 +673,23 @@ static int run_step(mlggd_engine *e, const Bunch &bn, bool prestaged = false, co
             else
                 CHK(launch_dw<1>(e, l, in_rows, !dp, nf, dws));
         }
-        if (dp) {
+        if (dp && !gather) {
             HIPCHK(hipEventRecord(e->ev_grad[l], dws));
             HIPCHK(hipStreamWaitEvent(e->comm_stream, e->ev_grad[l], 0));
             NCCLCHK(g_rccl.AllReduce(e->G[l], e->G[l], (size_t)Kp * Np, 7, 0, e->comm, e->comm_stream));
             HIPCHK(hipEventRecord(e->ev_red[l], e->comm_stream));
         }
     }
-    if (merged) {
+    if (gather) {
+        HIPCHK(hipEventRecord(e->ev_gathered, e->comm_stream));
+        HIPCHK(hipStreamWaitEvent(dws, e->ev_gathered, 0));
+        ProfScope ps(e, KC_DW, 1, dws);
+        CHK(launch_dwp(e, dwp_jobs_global(e, nf), true, dws, 1, e->world * Bp / 64));
+    } else if (merged) {
         ProfScope ps(e, KC_DW, 1, dws);
         CHK(launch_dwp(e, dwp_jobs(e, L - 1, 1, in_rows, nf), true, dws, 1));
     }
-    if (dp) {
+    if (dp && !gather) {
         // bias gradients were written by the dw kernels; ev_grad[1] is the last of them
         HIPCHK(hipStreamWaitEvent(e->comm_stream, e->ev_grad[1], 0));
         NCCLCHK(g_rccl.AllReduce(e->gb_all, e->gb_all, e->gb_all_count, 7, 0, e->comm, e->comm_stream));
@@ -748,6 +840,8 @@ int mlggd_destroy(mlggd_handle e) {
         if (e->ev_grad[l]) hipEventDestroy(e->ev_grad[l]);
         if (e->ev_red[l]) hipEventDestroy(e->ev_red[l]);
     }
+    if (e->ev_ready) hipEventDestroy(e->ev_ready);
+    if (e->ev_gathered) hipEventDestroy(e->ev_gathered);
     if (e->ev_bias) hipEventDestroy(e->ev_bias);
     if (e->ev_bias_red) hipEventDestroy(e->ev_bias_red);
     if (e->ev_t0) hipEventDestroy(e->ev_t0);
@@ -1171,6 +1265,7 @@ int mlggd_debug_tensor(mlggd_handle e, const char *name, int layer, float *dst, 
     }
     if (nm == "weights" || nm == "delta_w" || nm == "grad_w") {
         const float *src = (nm == "weights") ? e->W[layer] : (nm == "delta_w") ? e->dW[layer] : e->G[layer];
+        if (!src) return fail(MLGGD_ERR_STATE, "tensor %s does not exist on this path", name);
         if (!src) return fail(MLGGD_ERR_ARG, "%s not kept for layer %d", name, layer);
         CHK(need((size_t)K * N));
         CHK(download_padded(dst, src, Np, K, N, e->stream));
@@ -1212,7 +1307,15 @@ int mlggd_comm_init(mlggd_handle e, const void *id, int world_size, int rank) {
     e->world = world_size;
     e->rank = rank;
     HIPCHK(hipStreamCreateWithFlags(&e->comm_stream, hipStreamNonBlocking));
-    // gradient buffers (layer_ydedx / layer_sumdedx of BP_WorkSpace) only exist on this path
+    {
+        const char *m = getenv("MLGGD_DP_MODE");  // "gather" (default where usable) | "allreduce"
+        e->dp_mode = gather_usable(e, world_size) ? 1 : 0;
+        if (m && !strcmp(m, "allreduce")) e->dp_mode = 0;
+        if (m && !strcmp(m, "gather") && !gather_usable(e, world_size))
+            return fail(MLGGD_ERR_ARG, "MLGGD_DP_MODE=gather needs bunchsize %% 32 == 0 and world*bunchsize in {64,128,256,512,1024}");
+    }
+    if (e->dp_mode == 1) return gather_alloc(e);
+    // gradient buffers (layer_ydedx / layer_sumdedx of BP_WorkSpace) only exist on the all-reduce path
     size_t gbn = 0;
     for (int l = 1; l < e->L; l++) gbn += e->lsp[l];
     CHK(dev_alloc(e, &e->gb_all, gbn));
@@ -1227,6 +1330,28 @@ int mlggd_comm_init(mlggd_handle e, const void *id, int world_size, int rank) {
     }
     HIPCHK(hipEventCreateWithFlags(&e->ev_bias, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&e->ev_bias_red, hipEventDisableTiming));
+    return MLGGD_OK;
+}
+
+// Test hook: behave like rank 0 of `world_size` ranks that all hold the SAME minibatch, with device copies
+// in place of the collectives (no communicator, one GPU).  The result must equal the single-device step
+// with bunchsize world_size*B on the minibatch repeated world_size times -- the data-parallel contract.
+int mlggd_debug_fake_world(mlggd_handle e, int world_size) {
+    if (!e) return fail(MLGGD_ERR_ARG, "NULL handle");
+    if (e->comm || e->fake_world) return fail(MLGGD_ERR_STATE, "communicator already initialised");
+    if (world_size < 1 || !gather_usable(e, world_size))
+        return fail(MLGGD_ERR_ARG, "fake world of %d ranks: needs bunchsize %% 32 == 0 and world*bunchsize in {64,...,1024}", world_size);
+    HIPCHK(hipSetDevice(e->device));
+    e->world = world_size;
+    e->rank = 0;
+    e->fake_world = true;
+    e->dp_mode = 1;
+    HIPCHK(hipStreamCreateWithFlags(&e->comm_stream, hipStreamNonBlocking));
+    return gather_alloc(e);
+}
+int mlggd_dp_mode(mlggd_handle e, int *mode) {
+    if (!e || !mode) return fail(MLGGD_ERR_ARG, "NULL argument");
+    *mode = (e->comm || e->fake_world) ? 1 + e->dp_mode : 0;  // 0 single device, 1 all-reduce, 2 gather
     return MLGGD_OK;
 }
 
@@ -1346,7 +1471,8 @@ int mlggd_profile_overhead(mlggd_handle e, float *usec) {
 // one launch of the (class, layer) kernel; layer 0 = sum over layers.
 int mlggd_dw_launches_per_step(mlggd_handle e, int *launches) {
     if (!e || !launches) return fail(MLGGD_ERR_ARG, "NULL argument");
-    const bool merged = e->comm == nullptr && !e->two_streams && e->dw_merge && dwp_usable(e);
+    const bool dp = e->comm != nullptr || e->fake_world;
+    const bool merged = (!dp && !e->two_streams && e->dw_merge && dwp_usable(e)) || (dp && e->dp_mode == 1);
     *launches = merged ? 1 : e->L - 1;
     return MLGGD_OK;
 }
@@ -1354,7 +1480,9 @@ int mlggd_dw_launches_per_step(mlggd_handle e, int *launches) {
 int mlggd_kernel_work(mlggd_handle e, const char *kernel_class, int layer, double *flops, double *bytes) {
     if (!e || !kernel_class) return fail(MLGGD_ERR_ARG, "NULL argument");
     double f = 0, by = 0;
-    const double B = e->B;
+    // the gather path runs the dW kernel over the global minibatch on every rank
+    const bool global_dw = (e->comm != nullptr || e->fake_world) && e->dp_mode == 1 && !strcmp(kernel_class, "dw");
+    const double B = global_dw ? (double)e->B * e->world : (double)e->B;
     auto gemm = [&](const char *cls, int l, double &ff, double &bb) {
         if (l < 1 || l >= e->L) return;
         const double K = e->ls[l - 1], N = e->ls[l];

@@ -656,7 +656,9 @@ __device__ __forceinline__ void dwp_body(const DwpJobs &J, const int bid, const 
     const int B = J.job[0].B;
     const float nf = J.job[0].nf, mom = J.job[0].mom, lr = J.job[0].lr, wc = J.job[0].wc;
     constexpr int OOB = 0x7FFFFF00;  // byte offset beyond every descriptor: load -> 0, store dropped
-    constexpr int PPU = 8 / H;       // W/delta prefetch loads per unit (8 per tile and lane)
+    // W/delta prefetch: 8 loads per tile and lane, spread over the tile's units -- PPU per unit for
+    // H <= 8, one every H/8 units beyond that
+    constexpr int PPU = H <= 8 ? 8 / H : 1, PEVERY = H <= 8 ? 1 : H / 8;
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
     const int i = lane & 31, h5 = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
@@ -702,8 +704,8 @@ __device__ __forceinline__ void dwp_body(const DwpJobs &J, const int bid, const 
     {                                                                                           \
         if (FUSED) {                                                                            \
             const rsrc_t rW_ = make_rsrc(T.Wt, T.szW), rD_ = make_rsrc(T.delta, T.szW);         \
-            _Pragma("unroll") for (int jj = 0; jj < PPU; jj++) {                                \
-                const int j = (HH)*PPU + jj;                                                    \
+            _Pragma("unroll") for (int jj = 0; jj < ((HH) % PEVERY == 0 ? PPU : 0); jj++) {     \
+                const int j = ((HH) / PEVERY) * PPU + jj;                                       \
                 if (j < 4) PW[j] = bload4(rW_, DWP_OFF(T, j), 0);                               \
                 else PD[j - 4] = bload4(rD_, DWP_OFF(T, j - 4), 0);                             \
             }                                                                                   \

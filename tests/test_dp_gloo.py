@@ -2,8 +2,9 @@
 
 Each rank runs the oracle's phases on ITS rows of every global minibatch (rows chosen by the
 product's shard_rows), exchanges exactly what libmlggd.so exchanges over RCCL -- the
-per-dimension sum |e|^beta (ML only) and the weight/bias gradients, fp32 sum -- and applies
-the update with the GLOBAL minibatch size.  The result must equal a single-process run with
+per-dimension sum |e|^beta (ML only) and either the weight/bias gradients (fp32 sum, "allreduce")
+or their factors, the activations and dEdX of every rank ("gather") -- and applies the update with
+the GLOBAL minibatch size.  The result must equal a single-process run with
 bunchsize = world * B_local (up to summation order)."""
 import importlib
 import os
@@ -18,7 +19,7 @@ LS, BL, STEPS = [33, 24, 17, 11], 16, 3
 HP = (0.1, 0.9, 1e-5)
 
 
-def _worker(rank, world, ml, beta, initfile, outdir):
+def _worker(rank, world, ml, beta, initfile, outdir, mode="allreduce"):
     import torch
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
@@ -44,26 +45,46 @@ def _worker(rank, world, ml, beta, initfile, outdir):
         colsum = allreduce(net.loss_colsum(t)) if ml else np.zeros(LS[-1], np.float32)
         net.loss_grad(t, gb, colsum)
         net.backward(x)
-        # the engine all-reduces G_l / gb_l in place; here: write the reduced values back
         import ctypes as C
+
+        def grad_view(name, l):
+            cnt = C.c_long(0)
+            p = pyoracle.lib().ora_tensor(net._h, name.encode(), l, C.byref(cnt))
+            return np.ctypeslib.as_array(p, shape=(cnt.value,))
+
+        def allgather_rows(a):
+            t = torch.from_numpy(np.ascontiguousarray(a, np.float32))
+            out = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(out, t)
+            return np.concatenate([o.numpy() for o in out])  # rank-major rows = rows of the global minibatch
+
         for l in range(1, len(LS)):
-            for name in ("grad_w", "grad_b"):
-                cnt = C.c_long(0)
-                p = pyoracle.lib().ora_tensor(net._h, name.encode(), l, C.byref(cnt))
-                view = np.ctypeslib.as_array(p, shape=(cnt.value,))
-                view[:] = allreduce(view.copy())
+            if mode == "allreduce":
+                # the engine all-reduces G_l / gb_l in place; here: write the reduced values back
+                for name in ("grad_w", "grad_b"):
+                    view = grad_view(name, l)
+                    view[:] = allreduce(view.copy())
+            else:
+                # the engine all-gathers the FACTORS and every rank forms the global gradient itself
+                y_all = allgather_rows(x if l == 1 else net.tensor("y", l - 1, rows=BL))
+                d_all = allgather_rows(net.tensor("dedx", l, rows=BL))
+                grad_view("grad_w", l)[:] = (y_all.T.astype(np.float32) @ d_all.astype(np.float32)).ravel()
+                grad_view("grad_b", l)[:] = d_all.sum(axis=0, dtype=np.float32)
         net.apply_update(gb)
     w, b = net.get_weights()
     np.savez(os.path.join(outdir, "rank%d.npz" % rank), *w, *b, alpha=net.tensor("scalefactor"))
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("mode", ["allreduce", "gather"])
 @pytest.mark.parametrize("ml,beta", [(0, 2.0), (1, 1.2)])
-def test_two_ranks_equal_single_process_with_doubled_bunch(tmp_path, pyoracle, synth, ml, beta):
+def test_two_ranks_equal_single_process_with_doubled_bunch(tmp_path, pyoracle, synth, ml, beta, mode):
+    """mode = which exchange of libmlggd.so is mirrored: all-reduce of the gradients, or all-gather of
+    their factors (Y_{l-1}, dEdX_l) with the global gradient formed on every rank."""
     import torch.multiprocessing as mp
     world = 2
     initfile = str(tmp_path / "rendezvous")
-    mp.spawn(_worker, args=(world, ml, beta, initfile, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, ml, beta, initfile, str(tmp_path), mode), nprocs=world, join=True)
     ws, bs = synth.make_weights(LS, seed=8)
     inp, targ = synth.make_frames(STEPS * world * BL, 11, 3, seed=9)
     single = pyoracle.OracleNet(LS, world * BL, *HP, beta, ml, ws, bs)

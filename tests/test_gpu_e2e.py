@@ -71,22 +71,60 @@ def test_baseline_goldens(pkg, synth, ml, beta):
     eng.close()
 
 
+@pytest.mark.parametrize("mode", ["allreduce", "gather"])
 @pytest.mark.parametrize("ml,beta", [(0, 2.0), (1, 1.2)])
-def test_exchange_path_on_one_rank_communicator(pkg, pyoracle, synth, ml, beta):
-    """mlggd_comm_init(world=1): RCCL is dlopen'ed, the step runs the unfused kernels
-    (gradient buffers, all-reduce on the comm stream, k_apply_update) -- must equal the oracle."""
+def test_exchange_path_on_one_rank_communicator(pkg, pyoracle, synth, monkeypatch, ml, beta, mode):
+    """mlggd_comm_init(world=1): RCCL is dlopen'ed and the step takes a data-parallel exchange path --
+    allreduce: unfused kernels, gradient buffers, all-reduce on the comm stream, k_apply_update;
+    gather: all-gather of the gradient factors, then the fused kernel over the gathered minibatch --
+    and must equal the oracle."""
+    monkeypatch.setenv("MLGGD_DP_MODE", mode)
     ls, B = [257 * 3, 256, 160, 257], 64
     ws, bs = synth.make_weights(ls, seed=5)
     inp, targ = synth.make_frames(3 * B, 257, 3, seed=6)
     eng = pkg.BPGpu(1, 0, ls, B, *HP, ws, bs, beta, ml)
     eng.comm_init(pkg.comm_unique_id(), 1, 0)
+    assert eng.dp_mode() == (1 if mode == "allreduce" else 2)
     ora = pyoracle.OracleNet(ls, B, *HP, beta, ml, ws, bs)
     assert eng.train(inp, targ) == 3 and ora.train(inp, targ) == 3
     we, be = eng.returnWeights()
     wo, bo = ora.get_weights()
     for l in range(3):
         assert relmax(we[l], wo[l]) < 2e-5 and relmax(be[l], bo[l]) < 2e-5
-        assert relmax(eng.debug_tensor("grad_w", l + 1), ora.tensor("grad_w", l + 1)) < 3e-4
+        if mode == "allreduce":
+            assert relmax(eng.debug_tensor("grad_w", l + 1), ora.tensor("grad_w", l + 1)) < 3e-4
+    if ml:
+        assert relmax(eng.scalefactor(), ora.tensor("scalefactor")) < 1e-5
+    eng.close()
+
+
+@pytest.mark.parametrize("world,B", [(2, 64), (2, 128), (4, 128), (8, 128), (4, 32)])
+@pytest.mark.parametrize("ml,beta", [(0, 2.0), (1, 1.2)])
+def test_gather_exchange_equals_one_device_with_the_global_bunch(pkg, pyoracle, synth, ml, beta, world, B):
+    """SURVEY 8e parity definition: n ranks x B frames == one device with bunchsize n*B on the same
+    frame order.  `world` identical ranks are emulated on one GPU (device copies instead of RCCL), so
+    the global minibatch is the local one repeated `world` times; the oracle trains exactly that with
+    bunchsize world*B.  Covers the dW kernel over 2..16 units of 64 gathered frames."""
+    ls = [40 * 5, 160, 96, 40]
+    ws, bs = synth.make_weights(ls, seed=8)
+    rng = np.random.default_rng(9)
+    bs = [rng.uniform(-0.1, 0.1, b.shape).astype(np.float32) for b in bs]
+    steps = 2
+    inp, targ = synth.make_frames(steps * B, 40, 5, seed=10)
+    eng = pkg.BPGpu(1, 0, ls, B, *HP, ws, bs, beta, ml)
+    eng.fake_world(world)
+    assert eng.dp_mode() == 2
+    ora = pyoracle.OracleNet(ls, world * B, *HP, beta, ml, ws, bs)
+    gi = np.concatenate([np.tile(inp[s * B:(s + 1) * B], (world, 1)) for s in range(steps)])
+    gt = np.concatenate([np.tile(targ[s * B:(s + 1) * B], (world, 1)) for s in range(steps)])
+    assert eng.train(inp, targ) == steps and ora.train(gi, gt) == steps
+    we, be = eng.returnWeights()
+    wo, bo = ora.get_weights()
+    for l in range(len(we)):
+        assert relmax(we[l], wo[l]) < 2e-5, l
+        assert relmax(be[l], bo[l]) < 2e-5, l
+        assert relmax(eng.debug_tensor("delta_w", l + 1), ora.tensor("delta_w", l + 1)) < 2e-4, l
+        assert relmax(eng.debug_tensor("delta_b", l + 1), ora.tensor("delta_b", l + 1)) < 2e-4, l
     if ml:
         assert relmax(eng.scalefactor(), ora.tensor("scalefactor")) < 1e-5
     eng.close()
