@@ -139,12 +139,13 @@ def main():
             # which roof binds this kernel: arithmetic intensity against the machine balance
             # 157.3 TFLOP/s / 8 TB/s = 19.7 FLOP/B (at B = 128 the kernel moves 16 B per 2*B flops -> HBM)
             gbps = by / (us * 1e-6) / 1e9
-            gather = world > 1 and eng.dp_mode() == 2  # every rank runs the fused kernel over the gathered minibatch
-            units = max(1, ((B + 31) // 32 * 32) * (world if gather else 1) // 64)
+            mode = eng.dp_mode() if world > 1 else 0  # 2, 3: the fused kernel runs over the gathered minibatch
+            units = max(1, ((B + 31) // 32 * 32) * (world if mode >= 2 else 1) // 64)
             name = "k_dwp<%d,%s> (persistent dW GEMM + fused momentum/weight-decay/bias update, %s%s)" % (
-                units, "true" if (world == 1 or gather) else "false",
+                units, "true" if mode != 1 else "false",
                 "all layers in one launch" if nl == 1 else "one launch per layer",
-                ", over the %d gathered frames of all ranks" % (B * world) if gather else "")
+                {0: "", 1: "", 2: ", over the %d gathered frames of all ranks" % (B * world),
+                 3: ", this rank's block of weight rows over the %d gathered frames of all ranks" % (B * world)}[mode])
             if fl / by < MFMA_F32_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBPS * 1e9):
                 roofline = {"bound": "hbm", "kernel": name, "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS,
                             "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": traffic}
@@ -171,7 +172,8 @@ def main():
                    "layersizes": ls, "bunchsize_per_gpu": B, "global_minibatch": B * world,
                    "parallelism": "dp%d" % world, "flop_per_frame": fpf,
                    "dp_exchange": {0: None, 1: "all-reduce of weight gradients (RCCL)",
-                                   2: "all-gather of the gradient factors Y, dEdX (RCCL); every rank forms the global gradient"}[eng.dp_mode()]},
+                                   2: "all-gather of the gradient factors Y, dEdX (RCCL); every rank forms the global gradient",
+                                   3: "all-gather of the gradient factors Y, dEdX; each rank updates its block of weight rows; all-gather of W"}[eng.dp_mode()]},
         "step_roofline_frac": round(value * fpf / (world * MFMA_F32_PEAK_TFLOPS * 1e12), 4),
         "roofline": roofline,
     }
@@ -183,13 +185,13 @@ def main():
         t1 = time.perf_counter()
         ora.train_bunch(inp[:B], targ[:B])
         one = time.perf_counter() - t1
-        n = int(min(max(args.cpu_seconds / max(one, 1e-3), 4), min(nb, 200)))
+        n = int(min(max(args.cpu_seconds / max(one, 1e-4), 4), 20000))  # ~cpu_seconds of work, cycling the resident minibatches
         t1 = time.perf_counter()
         for i in range(n):
             ora.train_bunch(inp[(i % nb) * B:(i % nb + 1) * B], targ[(i % nb) * B:(i % nb + 1) * B])
         cdt = time.perf_counter() - t1
         out["cpu_baseline"] = {"value": round(n * B / cdt, 1), "unit": "frames/s", "cores": pyoracle.num_threads(),
-                               "kind": "port", "sample": "%d steps of the same %d-frame minibatches (oracle, OpenMP)"
+                               "kind": "port", "sample": "%d steps over the same %d-frame minibatches (oracle, OpenMP, threads = usable CPU share)"
                                % (n, B), "gpu_over_cpu": round(value / (n * B / cdt), 1)}
         ora.close()
     eng.close()

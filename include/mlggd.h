@@ -159,11 +159,13 @@ int mlggd_kernel_work(mlggd_handle h, const char *kernel_class, int layer, doubl
 /* how many launches of the weight-gradient/update kernel one training step issues: 1 when the
  * layers share one persistent launch (single GPU), numlayers-1 otherwise */
 int mlggd_dw_launches_per_step(mlggd_handle h, int *launches);
-/* 0 = single device, 1 = data parallel by all-reduce of the weight gradients, 2 = data parallel by
- * all-gather of their factors (default where usable; MLGGD_DP_MODE=allreduce|gather at comm init) */
+/* 0 = single device, 1 = data parallel by all-reduce of the weight gradients, 2 = by all-gather of their
+ * factors with the update replicated on every rank, 3 = the same with the update sharded over the ranks and
+ * W all-gathered (defaults: 2 up to 7 ranks, 3 from 8 ranks, 1 where the shape rules out the gather;
+ * MLGGD_DP_MODE=allreduce|gather|shard at comm init) */
 int mlggd_dp_mode(mlggd_handle h, int *mode);
 /* Test hook: emulate `world_size` identical ranks on one GPU (device copies instead of collectives). */
-int mlggd_debug_fake_world(mlggd_handle h, int world_size);
+int mlggd_debug_fake_world(mlggd_handle h, int world_size, int sharded);
 
 /* Diagnostic (not part of the reference surface): in-kernel phase stamps of the NEXT launch of
  * (class "fwd"|"dx"|"dw", layer): 8 int64 slots per workgroup in 100 MHz ticks

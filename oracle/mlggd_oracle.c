@@ -51,6 +51,14 @@ static float *zalloc(size_t n) { /* devnew_vf zero-fills, BP_GPU.cu:528-543 */
     return p;
 }
 
+void ora_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int ora_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -52,8 +52,39 @@ def lib():
         L.ora_tensor.restype = _fp
         L.ora_tensor.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_long)]
         L.ora_num_threads.restype = C.c_int
+        L.ora_set_num_threads.argtypes = [C.c_int]
+        if "OMP_NUM_THREADS" not in os.environ:
+            # a container often sees all host CPUs but may only use a share of them: more threads than
+            # that share makes every OpenMP region slower, not faster
+            L.ora_set_num_threads(usable_cpus())
         _lib = L
     return _lib
+
+
+def usable_cpus():
+    """CPUs this process may actually use: affinity mask and cgroup CPU quota (v2 and v1)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", None)):
+        try:
+            txt = open(path).read().strip()
+            if parse:
+                quota, period = parse(txt)
+                if quota != "max":
+                    n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+            else:
+                quota = int(txt)
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip())
+                if quota > 0 and period > 0:
+                    n = min(n, max(1, int(quota / period + 0.5)))
+            break
+        except (OSError, ValueError):
+            continue
+    return n
 
 
 def _f32(a):

@@ -104,7 +104,7 @@ def load():
                                     C.POINTER(C.c_double)]
     L.mlggd_dw_launches_per_step.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     L.mlggd_dp_mode.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
-    L.mlggd_debug_fake_world.argtypes = [C.c_void_p, C.c_int]
+    L.mlggd_debug_fake_world.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.mlggd_debug_stamp_select.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     L.mlggd_debug_stamp_read.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.c_int, C.POINTER(C.c_int)]
     _ip = C.POINTER(C.c_int32)
@@ -388,13 +388,13 @@ class BPGpu:
         return n.value
 
     def dp_mode(self):
-        """0 single device, 1 all-reduce of gradients, 2 all-gather of the gradient factors"""
+        """0 single device, 1 all-reduce of gradients, 2 all-gather of the gradient factors, 3 = 2 + sharded update"""
         n = C.c_int(0)
         _check(load().mlggd_dp_mode(self._h, C.byref(n)))
         return n.value
 
-    def fake_world(self, world_size):
-        _check(load().mlggd_debug_fake_world(self._h, int(world_size)))
+    def fake_world(self, world_size, sharded=False):
+        _check(load().mlggd_debug_fake_world(self._h, int(world_size), 1 if sharded else 0))
 
     def stamp_select(self, kernel_class, layer):
         _check(load().mlggd_debug_stamp_select(self._h, kernel_class.encode(), int(layer)))

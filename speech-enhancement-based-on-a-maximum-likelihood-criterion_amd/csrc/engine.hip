@@ -141,7 +141,10 @@ struct mlggd_engine {
     int world = 1, rank = 0;
     // data-parallel exchange: 0 = all-reduce of the weight gradients, 1 = all-gather of their FACTORS (the
     // activations Y_{l-1} and dEdX_l of every rank; each rank then forms the global-minibatch gradient itself)
-    int dp_mode = 0;
+    int dp_mode = 0;  // 2 = gather + SHARDED update: each rank updates its block of weight rows, then W is all-gathered
+    int shard_rows[MLGGD_MAXLAYER] = {0};  // 64-row tile rows of layer l owned by each rank
+    hipEvent_t ev_W[MLGGD_MAXLAYER] = {0}, ev_dw_done = nullptr;
+    bool ev_W_pending[MLGGD_MAXLAYER] = {false};
     bool fake_world = false;  // test hook: `world` identical ranks emulated with device copies, no communicator
     float *Yall[MLGGD_MAXLAYER] = {0}, *dEdXall[MLGGD_MAXLAYER] = {0};
     hipEvent_t ev_ready = nullptr, ev_gathered = nullptr;
@@ -293,6 +296,9 @@ static DwpArgs dwp_args(mlggd_engine *e, int l, const float *in_rows, const floa
     a.mom = e->cfg.momentum;
     a.lr = e->cfg.lrate;
     a.wc = e->cfg.weightcost;
+    a.k_first = 0;
+    a.wd_off = 0;
+    a.do_bias = 1;
     return a;
 }
 
@@ -345,6 +351,16 @@ static int run_transpose(mlggd_engine *e, const Bunch &bn, int frames) {
     return launch_check("k_transpose_in");
 }
 
+// every consumer of W on the main stream first waits for the all-gathers of the previous step
+static int wait_weight_gathers(mlggd_engine *e, int l_lo, int l_hi) {
+    for (int l = l_lo; l <= l_hi; l++)
+        if (e->ev_W_pending[l]) {
+            HIPCHK(hipStreamWaitEvent(e->stream, e->ev_W[l], 0));
+            e->ev_W_pending[l] = false;
+        }
+    return MLGGD_OK;
+}
+
 static int run_dropout(mlggd_engine *e, int layer, const float *chunk_rows) {
     // BP_GPU.cu:344-355: visible_omit on the input, hid_omit on hidden activations
     const float p = (layer == 0) ? e->cfg.visible_omit : e->cfg.hid_omit;
@@ -372,6 +388,7 @@ static int run_forward(mlggd_engine *e, const Bunch &bn, int frames, bool traini
     if (drop) CHK(run_dropout(e, 0, in_rows));
     for (int l = 1; l < e->L; l++) {
         const int Kp = e->lsp[l - 1], Np = e->lsp[l], n_tiles = Np / 32;
+        CHK(wait_weight_gathers(e, l, l));  // sharded data parallel: W_l of the previous step may still be arriving
         if (cvscale) {  // DevWeightMultiP before the GEMM, BP_GPU.cu:484-489
             const float keep = 1.0f - ((l == 1) ? e->cfg.visible_omit : e->cfg.hid_omit);
             hipLaunchKernelGGL(k_scale, dim3(1024), dim3(256), 0, e->stream, e->W[l], (size_t)Kp * Np, keep);
@@ -529,6 +546,69 @@ static int gather_end(mlggd_engine *e) {
     if (!e->fake_world) NCCLCHK(g_rccl.GroupEnd());
     return MLGGD_OK;
 }
+// ---- sharded update (dp_mode 2) --------------------------------------------------------------------
+// At 8 ranks the replicated dW launch is 8 x the MFMA work (298 us).  Here rank r forms only ITS block of
+// weight rows of every layer over the gathered minibatch -- 1/world of the tiles -- keeps delta for that
+// block only, and the updated W blocks are all-gathered in place, layer 1 first so that the next forward
+// pass starts as soon as W_1 has arrived.  W is allocated with world*shard rows (zero pad rows) so that
+// every rank's block has the same size.  Biases: the tiles of row block 0 run on every rank as bias-only
+// jobs (no W/delta access), so all ranks apply the identical bias update without another collective.
+static int shard_alloc(mlggd_engine *e) {
+    for (int l = 1; l < e->L; l++) {
+        const int Kp = e->lsp[l - 1], Np = e->lsp[l];
+        const int k_wg = (Kp + 63) / 64;
+        e->shard_rows[l] = (k_wg + e->world - 1) / e->world;
+        const size_t rows = (size_t)e->shard_rows[l] * 64 * e->world;
+        if (rows > (size_t)Kp) {  // grow W_l; the pad rows are never touched by a kernel (descriptors end at Kp)
+            float *nw = nullptr;
+            CHK(dev_alloc(e, &nw, rows * Np));
+            HIPCHK(hipMemcpyAsync(nw, e->W[l], (size_t)Kp * Np * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
+            HIPCHK(hipStreamSynchronize(e->stream));
+            e->W[l] = nw;  // the old buffer stays on the free list
+        }
+        HIPCHK(hipEventCreateWithFlags(&e->ev_W[l], hipEventDisableTiming));
+    }
+    HIPCHK(hipEventCreateWithFlags(&e->ev_dw_done, hipEventDisableTiming));
+    return MLGGD_OK;
+}
+// jobs of (virtual) rank r; with_bias_only: also the bias-only jobs of the layers whose row block 0 it
+// does not own; own_bias: whether its own row-block-0 job applies the bias update
+static DwpJobs dwp_jobs_shard(mlggd_engine *e, float nf, int r, bool with_bias_only, bool own_bias) {
+    DwpJobs G = dwp_jobs(e, e->L - 1, 1, e->Yall[0], nf), J;
+    memset(&J, 0, sizeof(J));
+    int nj = 0, end = 0;
+    // the full tiles first, the cheap bias-only tiles last: a workgroup that has to take a second tile
+    // then takes a cheap one
+    for (int pass = 0; pass < 2; pass++)
+        for (int j = 0; j < G.njobs; j++) {
+            const int l = e->L - 1 - j;
+            DwpArgs a = G.job[j];
+            a.Yrow = e->Yall[l - 1];
+            a.dEdX = e->dEdXall[l];
+            a.B = e->world * e->Bp;
+            const int k_wg = a.ntiles / a.n_wg;
+            const int kf = r * e->shard_rows[l];
+            const int kl = kf + e->shard_rows[l] < k_wg ? kf + e->shard_rows[l] : k_wg;
+            if (pass == 0 && kl > kf) {
+                a.k_first = kf;
+                a.ntiles = (kl - kf) * a.n_wg;
+                a.do_bias = (kf == 0 && own_bias) ? 1 : 0;
+            } else if (pass == 1 && kf != 0 && with_bias_only) {
+                a.k_first = 0;
+                a.ntiles = a.n_wg;
+                a.wd_off = 1;
+                a.do_bias = 1;
+            } else {
+                continue;
+            }
+            J.job[nj] = a;
+            end += a.ntiles;
+            J.tile_end[nj++] = end;
+        }
+    J.njobs = nj;
+    J.total = end;
+    return J;
+}
 static DwpJobs dwp_jobs_global(mlggd_engine *e, float nf) {
     DwpJobs J = dwp_jobs(e, e->L - 1, 1, e->Yall[0], nf);
     for (int j = 0; j < J.njobs; j++) {
@@ -568,7 +648,7 @@ static int run_step(mlggd_engine *e, const Bunch &bn, bool prestaged = false, co
     const float *targ_rows = bn.targ;
     const int L = e->L, B = e->B, Bp = e->Bp, b_tiles = Bp / 32;
     const bool dp = e->comm != nullptr || e->fake_world;  // a 1-rank communicator still takes the exchange path (tests)
-    const bool gather = dp && e->dp_mode == 1;
+    const bool gather = dp && e->dp_mode >= 1;
     const int n_global = B * e->world;
     const float nf = (float)n_global;
     const float inv_n = 1.0f / n_global;  // DevVecMulNum(..., 1.0f/n_frames, ...), BP_GPU.cu:409,423
@@ -578,12 +658,17 @@ static int run_step(mlggd_engine *e, const Bunch &bn, bool prestaged = false, co
     const float *in_rows = bunch_rows(e, bn);  // after run_forward: it may have switched in_bunch
     // input of the next step: Yt[0] is free from here on (forward_1 has been enqueued); frame-stream
     // rows go to the OTHER in_bunch buffer because this step's dW(1) still reads the current one
-    if (gather) {  // the forward factors travel while loss and dX run
+    // the forward factors travel while loss and dX run.  With the ML loss they are issued AFTER the loss
+    // kernels: the 257-float all-reduce of the loss statistic uses the same communicator, and collectives
+    // of one communicator run one after the other whatever stream they are on -- it must not queue behind
+    // megabytes of factors.
+    auto gather_forward_factors = [&]() -> int {
         CHK(gather_begin(e));
         CHK(gather_one(e, in_rows, e->Yall[0], (size_t)B * e->K0));
         for (int l = 1; l < L - 1; l++) CHK(gather_one(e, e->Y[l], e->Yall[l], (size_t)Bp * e->lsp[l]));
-        CHK(gather_end(e));
-    }
+        return gather_end(e);
+    };
+    if (gather && ML != 1) CHK(gather_forward_factors());
     StageArgs sa;
     memset(&sa, 0, sizeof(sa));
     int n_stage = 0;
@@ -627,6 +712,7 @@ static int run_step(mlggd_engine *e, const Bunch &bn, bool prestaged = false, co
             CHK(launch_check("k_loss_grad"));
         }
     }
+    if (gather && ML == 1) CHK(gather_forward_factors());
     const bool two = e->two_streams != 0;
     hipStream_t dws = two ? e->dw_stream : e->stream;
     // single GPU: every dW(l) only needs dEdX_l and Y_{l-1}, so one persistent launch walks the
@@ -680,7 +766,37 @@ static int run_step(mlggd_engine *e, const Bunch &bn, bool prestaged = false, co
             HIPCHK(hipEventRecord(e->ev_red[l], e->comm_stream));
         }
     }
-    if (gather) {
+    if (gather && e->dp_mode == 2) {
+        HIPCHK(hipEventRecord(e->ev_gathered, e->comm_stream));
+        HIPCHK(hipStreamWaitEvent(dws, e->ev_gathered, 0));
+        const int units = e->world * Bp / 64;
+        if (e->fake_world) {
+            // all virtual ranks in turn on this GPU: their row blocks are disjoint, so the union is the whole
+            // update; the bias update is taken from the LAST rank's bias-only jobs so that path is exercised
+            const char *only = getenv("MLGGD_FAKE_ONLY_RANK");  // timing: run one rank's share only (tools/dp_sim.py)
+            for (int r = 0; r < e->world; r++) {
+                if (only && atoi(only) != r) continue;
+                DwpJobs J = only ? dwp_jobs_shard(e, nf, r, true, true)
+                                 : dwp_jobs_shard(e, nf, r, r == e->world - 1, e->world == 1);
+                ProfScope ps(e, KC_DW, 1, dws);
+                if (J.total > 0) CHK(launch_dwp(e, J, true, dws, 1, units));
+            }
+        } else {
+            {
+                ProfScope ps(e, KC_DW, 1, dws);
+                DwpJobs J = dwp_jobs_shard(e, nf, e->rank, true, true);
+                if (J.total > 0) CHK(launch_dwp(e, J, true, dws, 1, units));
+            }
+            HIPCHK(hipEventRecord(e->ev_dw_done, dws));
+            HIPCHK(hipStreamWaitEvent(e->comm_stream, e->ev_dw_done, 0));
+            for (int l = 1; l < L; l++) {  // layer 1 first: the next forward pass needs it first
+                const size_t count = (size_t)e->shard_rows[l] * 64 * e->lsp[l];
+                NCCLCHK(g_rccl.AllGather(e->W[l] + (size_t)e->rank * count, e->W[l], count, 7, e->comm, e->comm_stream));
+                HIPCHK(hipEventRecord(e->ev_W[l], e->comm_stream));
+                e->ev_W_pending[l] = true;
+            }
+        }
+    } else if (gather) {
         HIPCHK(hipEventRecord(e->ev_gathered, e->comm_stream));
         HIPCHK(hipStreamWaitEvent(dws, e->ev_gathered, 0));
         ProfScope ps(e, KC_DW, 1, dws);
@@ -840,6 +956,9 @@ int mlggd_destroy(mlggd_handle e) {
         if (e->ev_grad[l]) hipEventDestroy(e->ev_grad[l]);
         if (e->ev_red[l]) hipEventDestroy(e->ev_red[l]);
     }
+    for (int l = 0; l < MLGGD_MAXLAYER; l++)
+        if (e->ev_W[l]) hipEventDestroy(e->ev_W[l]);
+    if (e->ev_dw_done) hipEventDestroy(e->ev_dw_done);
     if (e->ev_ready) hipEventDestroy(e->ev_ready);
     if (e->ev_gathered) hipEventDestroy(e->ev_gathered);
     if (e->ev_bias) hipEventDestroy(e->ev_bias);
@@ -859,6 +978,7 @@ int mlggd_destroy(mlggd_handle e) {
 int mlggd_set_weights(mlggd_handle e, const float *const *weights, const float *const *bias) {
     if (!e || !weights || !bias) return fail(MLGGD_ERR_ARG, "NULL argument");
     HIPCHK(hipSetDevice(e->device));
+    CHK(wait_weight_gathers(e, 1, e->L - 1));
     for (int l = 1; l < e->L; l++) {
         if (!weights[l] || !bias[l]) return fail(MLGGD_ERR_ARG, "weights[%d] or bias[%d] is NULL", l, l);
         CHK(upload_padded(e->W[l], e->lsp[l], weights[l], e->ls[l - 1], e->ls[l], e->stream));  // BP_GPU.cu:106
@@ -871,6 +991,7 @@ int mlggd_set_weights(mlggd_handle e, const float *const *weights, const float *
 int mlggd_get_weights(mlggd_handle e, float *const *weights, float *const *bias) {
     if (!e || !weights || !bias) return fail(MLGGD_ERR_ARG, "NULL argument");
     HIPCHK(hipSetDevice(e->device));
+    CHK(wait_weight_gathers(e, 1, e->L - 1));
     for (int l = 1; l < e->L; l++) {
         if (!weights[l] || !bias[l]) return fail(MLGGD_ERR_ARG, "weights[%d] or bias[%d] is NULL", l, l);
         CHK(download_padded(weights[l], e->W[l], e->lsp[l], e->ls[l - 1], e->ls[l], e->stream));  // BP_GPU.cu:522
@@ -1264,6 +1385,7 @@ int mlggd_debug_tensor(mlggd_handle e, const char *name, int layer, float *dst, 
         return MLGGD_OK;
     }
     if (nm == "weights" || nm == "delta_w" || nm == "grad_w") {
+        CHK(wait_weight_gathers(e, 1, L - 1));
         const float *src = (nm == "weights") ? e->W[layer] : (nm == "delta_w") ? e->dW[layer] : e->G[layer];
         if (!src) return fail(MLGGD_ERR_STATE, "tensor %s does not exist on this path", name);
         if (!src) return fail(MLGGD_ERR_ARG, "%s not kept for layer %d", name, layer);
@@ -1309,12 +1431,21 @@ int mlggd_comm_init(mlggd_handle e, const void *id, int world_size, int rank) {
     HIPCHK(hipStreamCreateWithFlags(&e->comm_stream, hipStreamNonBlocking));
     {
         const char *m = getenv("MLGGD_DP_MODE");  // "gather" (default where usable) | "allreduce"
-        e->dp_mode = gather_usable(e, world_size) ? 1 : 0;
+        // "gather" | "shard" | "allreduce"; default: gather where usable, sharded update from 6 ranks on
+        // (the W all-gather costs ~922/world us over world-1 links, the replicated update ~35 us per extra
+        // rank: DESIGN.md section 6)
+        e->dp_mode = gather_usable(e, world_size) ? (world_size >= 6 ? 2 : 1) : 0;
         if (m && !strcmp(m, "allreduce")) e->dp_mode = 0;
-        if (m && !strcmp(m, "gather") && !gather_usable(e, world_size))
-            return fail(MLGGD_ERR_ARG, "MLGGD_DP_MODE=gather needs bunchsize %% 32 == 0 and world*bunchsize in {64,128,256,512,1024}");
+        if (m && (!strcmp(m, "gather") || !strcmp(m, "shard"))) {
+            if (!gather_usable(e, world_size))
+                return fail(MLGGD_ERR_ARG, "MLGGD_DP_MODE=%s needs bunchsize %% 32 == 0 and world*bunchsize in {64,128,256,512,1024}", m);
+            e->dp_mode = !strcmp(m, "shard") ? 2 : 1;
+        }
     }
-    if (e->dp_mode == 1) return gather_alloc(e);
+    if (e->dp_mode >= 1) {
+        CHK(gather_alloc(e));
+        return e->dp_mode == 2 ? shard_alloc(e) : MLGGD_OK;
+    }
     // gradient buffers (layer_ydedx / layer_sumdedx of BP_WorkSpace) only exist on the all-reduce path
     size_t gbn = 0;
     for (int l = 1; l < e->L; l++) gbn += e->lsp[l];
@@ -1336,7 +1467,7 @@ int mlggd_comm_init(mlggd_handle e, const void *id, int world_size, int rank) {
 // Test hook: behave like rank 0 of `world_size` ranks that all hold the SAME minibatch, with device copies
 // in place of the collectives (no communicator, one GPU).  The result must equal the single-device step
 // with bunchsize world_size*B on the minibatch repeated world_size times -- the data-parallel contract.
-int mlggd_debug_fake_world(mlggd_handle e, int world_size) {
+int mlggd_debug_fake_world(mlggd_handle e, int world_size, int sharded) {
     if (!e) return fail(MLGGD_ERR_ARG, "NULL handle");
     if (e->comm || e->fake_world) return fail(MLGGD_ERR_STATE, "communicator already initialised");
     if (world_size < 1 || !gather_usable(e, world_size))
@@ -1345,13 +1476,14 @@ int mlggd_debug_fake_world(mlggd_handle e, int world_size) {
     e->world = world_size;
     e->rank = 0;
     e->fake_world = true;
-    e->dp_mode = 1;
+    e->dp_mode = sharded ? 2 : 1;
     HIPCHK(hipStreamCreateWithFlags(&e->comm_stream, hipStreamNonBlocking));
-    return gather_alloc(e);
+    CHK(gather_alloc(e));
+    return sharded ? shard_alloc(e) : MLGGD_OK;
 }
 int mlggd_dp_mode(mlggd_handle e, int *mode) {
     if (!e || !mode) return fail(MLGGD_ERR_ARG, "NULL argument");
-    *mode = (e->comm || e->fake_world) ? 1 + e->dp_mode : 0;  // 0 single device, 1 all-reduce, 2 gather
+    *mode = (e->comm || e->fake_world) ? 1 + e->dp_mode : 0;  // 0 single device, 1 all-reduce, 2 gather, 3 gather + sharded update
     return MLGGD_OK;
 }
 
@@ -1472,7 +1604,7 @@ int mlggd_profile_overhead(mlggd_handle e, float *usec) {
 int mlggd_dw_launches_per_step(mlggd_handle e, int *launches) {
     if (!e || !launches) return fail(MLGGD_ERR_ARG, "NULL argument");
     const bool dp = e->comm != nullptr || e->fake_world;
-    const bool merged = (!dp && !e->two_streams && e->dw_merge && dwp_usable(e)) || (dp && e->dp_mode == 1);
+    const bool merged = (!dp && !e->two_streams && e->dw_merge && dwp_usable(e)) || (dp && e->dp_mode >= 1);
     *launches = merged ? 1 : e->L - 1;
     return MLGGD_OK;
 }
@@ -1481,8 +1613,10 @@ int mlggd_kernel_work(mlggd_handle e, const char *kernel_class, int layer, doubl
     if (!e || !kernel_class) return fail(MLGGD_ERR_ARG, "NULL argument");
     double f = 0, by = 0;
     // the gather path runs the dW kernel over the global minibatch on every rank
-    const bool global_dw = (e->comm != nullptr || e->fake_world) && e->dp_mode == 1 && !strcmp(kernel_class, "dw");
-    const double B = global_dw ? (double)e->B * e->world : (double)e->B;
+    // the gather paths run the dW kernel over the global minibatch: replicated (dp_mode 1) on all tiles,
+    // sharded (dp_mode 2) on this rank's 1/world of the weight rows
+    const bool dpx = (e->comm != nullptr || e->fake_world) && e->dp_mode >= 1 && !strcmp(kernel_class, "dw");
+    const double W = e->world, B = e->B;
     auto gemm = [&](const char *cls, int l, double &ff, double &bb) {
         if (l < 1 || l >= e->L) return;
         const double K = e->ls[l - 1], N = e->ls[l];
@@ -1494,8 +1628,16 @@ int mlggd_kernel_work(mlggd_handle e, const char *kernel_class, int layer, doubl
             ff += 2.0 * B * K * N;
             bb += 4.0 * (K * N + B * N + 3 * B * K);
         } else if (!strcmp(cls, "dw")) {
-            ff += 2.0 * B * K * N;
-            bb += 4.0 * (4 * K * N + B * K + B * N);  // W, delta read + written
+            if (!dpx) {
+                ff += 2.0 * B * K * N;
+                bb += 4.0 * (4 * K * N + B * K + B * N);  // W, delta read + written
+            } else if (e->dp_mode == 1) {
+                ff += 2.0 * B * W * K * N;
+                bb += 4.0 * (4 * K * N + B * W * K + B * W * N);
+            } else {
+                ff += 2.0 * B * W * K * N / W;
+                bb += 4.0 * (4 * K * N / W + B * W * K / W + B * W * N);
+            }
         }
     };
     for (int l = 1; l < e->L; l++) {

@@ -607,10 +607,15 @@ struct DwpArgs {
     float *Wt, *delta, *G, *bias, *dbias, *gb;
     int ldA, K, N, Kp, Np, B, n_wg, ntiles;
     float nf, mom, lr, wc;
+    // sharded data parallel: the job covers tile rows k_first .. of the layer;
+    // wd_off = 1 makes it a bias-only job (W/delta are neither read nor written: the tiles of weight
+    // row block 0 run on every rank so that every rank applies the same bias update); do_bias = 0
+    // suppresses the bias update of a job that does own row block 0
+    int k_first, wd_off, do_bias;
 };
 // One launch may walk the tiles of several layers (every dW(l) only needs dEdX_l and Y_{l-1}, both
 // final once the last dX has run): job j owns the global tile numbers [tile_end[j-1], tile_end[j]).
-constexpr int DWP_MAXJOBS = 10;
+constexpr int DWP_MAXJOBS = 20;
 struct DwpJobs {
     DwpArgs job[DWP_MAXJOBS];
     int tile_end[DWP_MAXJOBS];
@@ -639,12 +644,13 @@ __device__ __forceinline__ DwpTile dwp_locate(const DwpJobs &J, const int t, con
     const int tl = valid ? t - first : 0;
     T.Yrow = A.Yrow; T.dEdX = A.dEdX; T.Wt = A.Wt; T.delta = A.delta; T.G = A.G;
     T.bias = A.bias; T.dbias = A.dbias; T.gb = A.gb;
-    T.ldA = A.ldA; T.K = A.K; T.N = A.N; T.Np = A.Np;
-    T.k0 = (tl / A.n_wg) * 64;
+    T.ldA = A.ldA; T.K = A.K; T.Np = A.Np;
+    T.N = A.do_bias ? A.N : 0;  // N only bounds the bias update
+    T.k0 = (A.k_first + tl / A.n_wg) * 64;
     T.n0 = (tl % A.n_wg) * 64;
     T.szA = valid ? (unsigned)Bp * A.ldA * 4u : 0u;
     T.szB = valid ? (unsigned)Bp * A.Np * 4u : 0u;
-    T.szW = valid ? (unsigned)A.Kp * A.Np * 4u : 0u;
+    T.szW = (valid && !A.wd_off) ? (unsigned)A.Kp * A.Np * 4u : 0u;
     return T;
 }
 
@@ -715,7 +721,8 @@ __device__ __forceinline__ void dwp_body(const DwpJobs &J, const int bid, const 
     {                                                                                           \
         const float *ap = lds + (BUF)*8192 + h5 * 64 + 32 * wm + i;                             \
         const float *bp = lds + (BUF)*8192 + 4096 + h5 * 64 + 32 * wn + i;                      \
-        _Pragma("unroll") for (int p = 0; p < 32; p++) acc = mfma32(ap[p * 128], bp[p * 128], acc); \
+        /* bias-only tiles (szW == 0) have nothing to multiply */                               \
+        if (tc.szW != 0) { _Pragma("unroll") for (int p = 0; p < 32; p++) acc = mfma32(ap[p * 128], bp[p * 128], acc); } \
     }
 #define DWP_BIAS(BUF, HH)                                                                       \
     {                                                                                           \

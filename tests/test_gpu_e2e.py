@@ -71,20 +71,21 @@ def test_baseline_goldens(pkg, synth, ml, beta):
     eng.close()
 
 
-@pytest.mark.parametrize("mode", ["allreduce", "gather"])
+@pytest.mark.parametrize("mode", ["allreduce", "gather", "shard"])
 @pytest.mark.parametrize("ml,beta", [(0, 2.0), (1, 1.2)])
 def test_exchange_path_on_one_rank_communicator(pkg, pyoracle, synth, monkeypatch, ml, beta, mode):
     """mlggd_comm_init(world=1): RCCL is dlopen'ed and the step takes a data-parallel exchange path --
     allreduce: unfused kernels, gradient buffers, all-reduce on the comm stream, k_apply_update;
-    gather: all-gather of the gradient factors, then the fused kernel over the gathered minibatch --
-    and must equal the oracle."""
+    gather: all-gather of the gradient factors, then the fused kernel over the gathered minibatch;
+    shard: the same with the update restricted to the rank's block of weight rows and W all-gathered in
+    place -- and must equal the oracle."""
     monkeypatch.setenv("MLGGD_DP_MODE", mode)
     ls, B = [257 * 3, 256, 160, 257], 64
     ws, bs = synth.make_weights(ls, seed=5)
     inp, targ = synth.make_frames(3 * B, 257, 3, seed=6)
     eng = pkg.BPGpu(1, 0, ls, B, *HP, ws, bs, beta, ml)
     eng.comm_init(pkg.comm_unique_id(), 1, 0)
-    assert eng.dp_mode() == (1 if mode == "allreduce" else 2)
+    assert eng.dp_mode() == {"allreduce": 1, "gather": 2, "shard": 3}[mode]
     ora = pyoracle.OracleNet(ls, B, *HP, beta, ml, ws, bs)
     assert eng.train(inp, targ) == 3 and ora.train(inp, targ) == 3
     we, be = eng.returnWeights()
@@ -98,13 +99,16 @@ def test_exchange_path_on_one_rank_communicator(pkg, pyoracle, synth, monkeypatc
     eng.close()
 
 
+@pytest.mark.parametrize("sharded", [False, True])
 @pytest.mark.parametrize("world,B", [(2, 64), (2, 128), (4, 128), (8, 128), (4, 32)])
 @pytest.mark.parametrize("ml,beta", [(0, 2.0), (1, 1.2)])
-def test_gather_exchange_equals_one_device_with_the_global_bunch(pkg, pyoracle, synth, ml, beta, world, B):
+def test_gather_exchange_equals_one_device_with_the_global_bunch(pkg, pyoracle, synth, ml, beta, world, B, sharded):
     """SURVEY 8e parity definition: n ranks x B frames == one device with bunchsize n*B on the same
     frame order.  `world` identical ranks are emulated on one GPU (device copies instead of RCCL), so
     the global minibatch is the local one repeated `world` times; the oracle trains exactly that with
-    bunchsize world*B.  Covers the dW kernel over 2..16 units of 64 gathered frames."""
+    bunchsize world*B.  Covers the dW kernel over 2..16 units of 64 gathered frames.  sharded: every
+    emulated rank updates only its block of weight rows (all of them run in turn on this GPU, the bias
+    update comes from the last rank's bias-only jobs); layer sizes give uneven and empty blocks."""
     ls = [40 * 5, 160, 96, 40]
     ws, bs = synth.make_weights(ls, seed=8)
     rng = np.random.default_rng(9)
@@ -112,8 +116,8 @@ def test_gather_exchange_equals_one_device_with_the_global_bunch(pkg, pyoracle, 
     steps = 2
     inp, targ = synth.make_frames(steps * B, 40, 5, seed=10)
     eng = pkg.BPGpu(1, 0, ls, B, *HP, ws, bs, beta, ml)
-    eng.fake_world(world)
-    assert eng.dp_mode() == 2
+    eng.fake_world(world, sharded)
+    assert eng.dp_mode() == (3 if sharded else 2)
     ora = pyoracle.OracleNet(ls, world * B, *HP, beta, ml, ws, bs)
     gi = np.concatenate([np.tile(inp[s * B:(s + 1) * B], (world, 1)) for s in range(steps)])
     gt = np.concatenate([np.tile(targ[s * B:(s + 1) * B], (world, 1)) for s in range(steps)])

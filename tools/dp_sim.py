@@ -1,8 +1,7 @@
 #!/usr/bin/env python3
 """Compute-side cost of the data-parallel step on ONE GPU: `world` identical ranks are emulated (device
 copies instead of RCCL), so this shows what the gather exchange costs in kernels -- the dW kernel over the
-global minibatch -- not what the links cost.  us/step, and frames/s the job would reach if the exchange
-were free."""
+global minibatch -- not what the links cost."""
 import importlib, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,16 +10,18 @@ pkg = importlib.import_module(PKG); synth = importlib.import_module(PKG + ".synt
 ls = synth.baseline_layersizes(); B = 128
 ws, bs = synth.make_weights(ls); NB = 32
 inp, targ = synth.make_frames(NB * B, 257, 11)
-for world in (1, 2, 4, 8):
+for world, sharded in ((1, False), (2, False), (4, False), (8, False), (8, True), (4, True)):
+    if sharded:
+        os.environ["MLGGD_FAKE_ONLY_RANK"] = "3"  # time ONE rank's share (a rank that also runs the bias-only tiles)
     eng = pkg.BPGpu(1, 0, ls, B, 0.1, 0.9, 1e-5, ws, bs, 2.0, 0)
     if world > 1:
-        eng.fake_world(world)
+        eng.fake_world(world, sharded)
     eng.load_chunk(inp, targ)
     eng.train_resident(0, NB * B); eng.sync()
     t0 = time.perf_counter()
     for _ in range(8): eng.train_resident(0, NB * B)
     eng.sync(); dt = (time.perf_counter() - t0) / (8 * NB)
     eng.profile_select("dw", 0, 4096); eng.train_resident(0, NB * B); us, n = eng.profile_read(); eng.profile_select(None)
-    print("world %d: %.1f us/step (dW launch %.1f us incl. ~3.8 us bracket) -> %.0f k frames/s for the job if the exchange is hidden"
-          % (world, dt * 1e6, us, world * B / dt / 1e3), flush=True)
+    print("world %d%s: %.1f us/step with the emulated exchange (device copies); dW launch %.1f us incl. ~3.8 us bracket"
+          % (world, " sharded update (rank 3's share only; W all-gather not emulated)" if sharded else "", dt * 1e6, us), flush=True)
     eng.close()
