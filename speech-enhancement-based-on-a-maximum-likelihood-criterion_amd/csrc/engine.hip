@@ -375,13 +375,24 @@ static int run_dropout(mlggd_engine *e, int layer, const float *chunk_rows) {
 
 // prestaged: Yt[0] (and, for frame-stream chunks, the other in_bunch buffer) already hold this
 // bunch -- the previous training step staged it alongside its loss kernel
-static int run_forward(mlggd_engine *e, const Bunch &bn, int frames, bool training, bool prestaged = false) {
+static int gather_begin(mlggd_engine *e);
+static int gather_end(mlggd_engine *e);
+static int gather_one(mlggd_engine *e, const float *src, float *dst, size_t count);
+enum { GATHER_INPUT = 1, GATHER_HIDDEN = 2 };  // data-parallel factor exchange issued from inside the forward pass
+
+static int run_forward(mlggd_engine *e, const Bunch &bn, int frames, bool training, bool prestaged = false,
+                       int gather_flags = 0) {
     if (prestaged) {
         if (bn.first) e->in_bunch = in_bunch_other(e);
     } else {
         CHK(run_transpose(e, bn, frames));
     }
     const float *in_rows = bunch_rows(e, bn);
+    if (gather_flags & GATHER_INPUT) {  // the input rows can travel from the first microsecond of the step
+        CHK(gather_begin(e));
+        CHK(gather_one(e, in_rows, e->Yall[0], (size_t)frames * e->K0));
+        CHK(gather_end(e));
+    }
     const int b_tiles = e->Bp / 32;
     const bool drop = training && e->cfg.dropoutflag == 1;
     const bool cvscale = !training && e->cfg.dropoutflag == 1;
@@ -420,6 +431,11 @@ static int run_forward(mlggd_engine *e, const Bunch &bn, int frames, bool traini
             hipLaunchKernelGGL(k_scale, dim3(1024), dim3(256), 0, e->stream, e->W[l], (size_t)Kp * Np, 1.0f / keep);
         }
         if (drop && l != e->L - 1) CHK(run_dropout(e, l, nullptr));
+        if ((gather_flags & GATHER_HIDDEN) && l == e->L - 2) {  // all hidden activations exist: send them
+            CHK(gather_begin(e));                               // beside the output layer, the loss and dX
+            for (int g = 1; g < e->L - 1; g++) CHK(gather_one(e, e->Y[g], e->Yall[g], (size_t)e->Bp * e->lsp[g]));
+            CHK(gather_end(e));
+        }
     }
     return MLGGD_OK;
 }
@@ -654,21 +670,14 @@ static int run_step(mlggd_engine *e, const Bunch &bn, bool prestaged = false, co
     const float inv_n = 1.0f / n_global;  // DevVecMulNum(..., 1.0f/n_frames, ...), BP_GPU.cu:409,423
     const int ML = e->cfg.MLflag;
 
-    CHK(run_forward(e, bn, B, true, prestaged));
+    // With the ML loss the hidden activations are sent AFTER the loss kernels: the 257-float all-reduce of the
+    // loss statistic uses the same communicator, and collectives of one communicator run one after the other
+    // whatever stream they are on -- it must not queue behind megabytes of factors (the input rows, sent at
+    // the start of the step, have long arrived by then).
+    CHK(run_forward(e, bn, B, true, prestaged, gather ? (GATHER_INPUT | (ML != 1 ? GATHER_HIDDEN : 0)) : 0));
     const float *in_rows = bunch_rows(e, bn);  // after run_forward: it may have switched in_bunch
     // input of the next step: Yt[0] is free from here on (forward_1 has been enqueued); frame-stream
     // rows go to the OTHER in_bunch buffer because this step's dW(1) still reads the current one
-    // the forward factors travel while loss and dX run.  With the ML loss they are issued AFTER the loss
-    // kernels: the 257-float all-reduce of the loss statistic uses the same communicator, and collectives
-    // of one communicator run one after the other whatever stream they are on -- it must not queue behind
-    // megabytes of factors.
-    auto gather_forward_factors = [&]() -> int {
-        CHK(gather_begin(e));
-        CHK(gather_one(e, in_rows, e->Yall[0], (size_t)B * e->K0));
-        for (int l = 1; l < L - 1; l++) CHK(gather_one(e, e->Y[l], e->Yall[l], (size_t)Bp * e->lsp[l]));
-        return gather_end(e);
-    };
-    if (gather && ML != 1) CHK(gather_forward_factors());
     StageArgs sa;
     memset(&sa, 0, sizeof(sa));
     int n_stage = 0;
@@ -712,7 +721,11 @@ static int run_step(mlggd_engine *e, const Bunch &bn, bool prestaged = false, co
             CHK(launch_check("k_loss_grad"));
         }
     }
-    if (gather && ML == 1) CHK(gather_forward_factors());
+    if (gather && ML == 1 && L > 2) {
+        CHK(gather_begin(e));
+        for (int g = 1; g < L - 1; g++) CHK(gather_one(e, e->Y[g], e->Yall[g], (size_t)Bp * e->lsp[g]));
+        CHK(gather_end(e));
+    }
     const bool two = e->two_streams != 0;
     hipStream_t dws = two ? e->dw_stream : e->stream;
     // single GPU: every dW(l) only needs dEdX_l and Y_{l-1}, so one persistent launch walks the
