@@ -18,6 +18,7 @@
 // WORLD_SIZE*bunchsize samples; rank 0 alone writes the log, the weights and runs CV.
 #include <chrono>
 #include <condition_variable>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -71,11 +72,14 @@ void swap_buffers(Interface *io, bool frames) {  // BPtrain.cc:25-32
 }
 
 // threadFetch, BPtrain.cc:15-54
+std::atomic<bool> g_stop_fetch{false};  // set when the trainer gives up before consuming every chunk
+
 void fetch_loop(Interface *io, Slot *slot, std::string *error, bool frames) {
     try {
-        for (unsigned i = 0; i < io->total_chunks; i++) {
+        for (unsigned i = 0; i < io->total_chunks && !g_stop_fetch; i++) {
             const int n = frames ? io->Readchunk_frames(io->chunk_index[i]) : io->Readchunk(io->chunk_index[i]);
             if (i > 0) slot->wait(false);                      // trainer done with indata[1]
+            if (g_stop_fetch) break;
             io->cur_chunk_samples = n;
             swap_buffers(io, frames);
             slot->set(true);
@@ -119,15 +123,65 @@ void exchange_id(int rank, unsigned char id[MLGGD_UNIQUE_ID_BYTES]) {
 
 }  // namespace
 
+// MLGGD_TIMING=1: wall-clock of the phases on stderr (where does an epoch of the executable go?)
+static double now_s() {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+static void phase(const char *name, double &t_last) {
+    static const bool on = getenv("MLGGD_TIMING") != nullptr;
+    const double t = now_s();
+    if (on) fprintf(stderr, "[timing] %-28s %8.3f s\n", name, t - t_last);
+    t_last = t;
+}
+
 int main(int argc, char *argv[]) {
     const double t_start = (double)time(NULL);
+    double t_phase = now_s();
     printf("--------activation functin is sigmoid--------\n");  // BPtrain.cc:71
     const int world = env_int("WORLD_SIZE", 1), rank = env_int("RANK", 0);
     const int local_rank = env_int("LOCAL_RANK", rank);
     Interface *io = new Interface;
     try {
         io->Initial(argc, argv, /*open_output=*/rank == 0);
+        phase("arguments, norm, init weights", t_phase);
         WorkPara *p = io->para;
+        // ---- train (BPtrain.cc:81-102).  The chunk plan and the fetch thread only touch host state, so the
+        // first chunk is read while the engine initialises HIP and uploads the weights (the reference creates
+        // BP_GPU first, BPtrain.cc:77-78, and reads the first chunk afterwards).
+        io->get_pfile_info();
+        io->get_chunk_info(p->train_sent_range);
+        io->chunk_index.resize(io->total_chunks);
+        for (unsigned i = 0; i < io->total_chunks; i++) io->chunk_index[i] = (int)i;
+        io->GetRandIndex(io->chunk_index.data(), (int)io->total_chunks);
+
+        Slot slot;
+        std::string fetch_error;
+        const bool frames = env_int("MLGGD_EXPANDED", 0) == 0;
+        // page-locked chunk buffers: the per-chunk upload of ~200 MB runs at DMA speed instead of through
+        // the runtime's staging copies
+        if (frames && env_int("MLGGD_PINNED", 1))
+            io->set_buffer_allocator(
+                [](size_t n) -> void * {
+                    void *q = nullptr;
+                    return mlggd_alloc_pinned(n, &q) == MLGGD_OK ? q : nullptr;
+                },
+                [](void *q) { mlggd_free_pinned(q); });
+        std::thread fetch(fetch_loop, io, &slot, &fetch_error, frames);
+        struct FetchGuard {  // any exception from here on: stop and join the reader before unwinding
+            std::thread &t;
+            Slot &s;
+            ~FetchGuard() {
+                if (t.joinable()) {
+                    g_stop_fetch = true;
+                    s.set(false);
+                    t.join();
+                }
+            }
+        } fetch_guard{fetch, slot};
+        phase("pfile headers, chunk plan", t_phase);
+
         const int device = world > 1 ? local_rank : p->gpu_used;
         BP_GPU *net = new BP_GPU(p->init_randem_seed, device, io->numlayers, p->layersizes, p->bunchsize, p->lrate,
                                  p->momentum, p->weightcost, p->weights, p->bias, p->shapefactor, p->MLflag,
@@ -137,18 +191,7 @@ int main(int argc, char *argv[]) {
             exchange_id(rank, id);
             net->joinComm(id, world, rank);
         }
-        io->get_pfile_info();
-
-        // ---- train (BPtrain.cc:81-102)
-        io->get_chunk_info(p->train_sent_range);
-        io->chunk_index.resize(io->total_chunks);
-        for (unsigned i = 0; i < io->total_chunks; i++) io->chunk_index[i] = (int)i;
-        io->GetRandIndex(io->chunk_index.data(), (int)io->total_chunks);
-
-        Slot slot;
-        std::string fetch_error;
-        const bool frames = env_int("MLGGD_EXPANDED", 0) == 0;
-        std::thread fetch(fetch_loop, io, &slot, &fetch_error, frames);
+        phase("engine (HIP init, upload)", t_phase);
         const int K0 = p->layersizes[0], D = p->layersizes[io->numlayers - 1], B = p->bunchsize;
         std::vector<float> loc_in, loc_targ;
         for (unsigned i = 0; i < io->total_chunks; i++) {
@@ -189,6 +232,7 @@ int main(int argc, char *argv[]) {
         }
         fetch.join();
         if (!fetch_error.empty()) throw IoError(fetch_error);
+        phase("training chunks", t_phase);
 
         io->logf("Total cost time: %.1f s.\n", (double)time(NULL) - t_start);  // BPtrain.cc:104-105
 
@@ -197,6 +241,7 @@ int main(int argc, char *argv[]) {
             net->returnWeights(p->weights, p->bias);
             io->Writeweights();
             printf("finish to write weights\n\n");
+            phase("download + write weights", t_phase);
 
             // ---- CV (BPtrain.cc:112-140)
             printf("begin to CV\n");
@@ -228,10 +273,12 @@ int main(int argc, char *argv[]) {
                 io->logf("CV2 over. CV log likelihood: %f\n", cvacc2);
             }
             if (io->fp_log) fflush(io->fp_log);
+            phase("cross validation", t_phase);
         }
         printf("all finish!\n");
         delete net;
         delete io;
+        phase("teardown", t_phase);
     } catch (const std::exception &e) {
         // the reference writes the message to the log and exit(0)s (e.g. Interface.cc:320,325,451);
         // same message, non-zero status

@@ -6,6 +6,8 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
+#include <sched.h>
 
 namespace mlggd_host {
 
@@ -46,9 +48,47 @@ void parse_range(const std::string &range, int &st, int &en, bool &ok) {
 
 }  // namespace
 
-Interface::Interface() : para(new WorkPara) {}
+// CPUs this process may really use: affinity mask and cgroup quota (a container often shows every host CPU)
+static int usable_cpus() {
+    int n = (int)std::thread::hardware_concurrency();
+    if (n < 1) n = 1;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) {
+        const int c = CPU_COUNT(&set);
+        if (c > 0 && c < n) n = c;
+    }
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char quota[64];
+        long period = 0;
+        if (fscanf(f, "%63s %ld", quota, &period) == 2 && strcmp(quota, "max") != 0 && period > 0) {
+            const int c = (int)((atof(quota) / (double)period) + 0.5);
+            if (c >= 1 && c < n) n = c;
+        }
+        fclose(f);
+    }
+    return n;
+}
+
+Interface::Interface() : para(new WorkPara) {
+    io_threads_ = usable_cpus();
+    if (io_threads_ > 16) io_threads_ = 16;
+    if (const char *v = getenv("MLGGD_IO_THREADS")) io_threads_ = atoi(v) > 0 ? atoi(v) : 1;
+}
+
+void *Interface::ensure(HostBuf &b, size_t bytes) {
+    if (b.bytes >= bytes && b.p) return b.p;
+    if (b.p) (buf_free_ ? buf_free_ : free)(b.p);
+    const size_t want = bytes + bytes / 16 + 4096;  // chunks differ a little in length: avoid regrowing every time
+    b.p = buf_alloc_ ? buf_alloc_(want) : malloc(want);
+    if (!b.p) throw IoError("out of host memory for a chunk buffer");
+    b.bytes = want;
+    return b.p;
+}
 
 Interface::~Interface() {
+    for (HostBuf *set : {fr_in_, fr_targ_, fr_first_})
+        for (int i = 0; i < 2; i++)
+            if (set[i].p) (buf_free_ ? buf_free_ : free)(set[i].p);
     if (fp_data) fclose(fp_data);
     if (fp_targ) fclose(fp_targ);
     if (fp_log) fclose(fp_log);
@@ -412,23 +452,35 @@ int Interface::read_chunk(const ChunkPlan &plan, int index, bool shuffle, bool e
     for (int i = 0; i < samples; i++) order[i] = i;
     if (shuffle) GetRandIndex(order.data(), samples);  // Interface.cc:754 (train only)
 
-    auto load = [&](FILE *fp, int ncol, std::vector<float> &vals, int &first_sent) {
+    // fread the chunk's rows, then byte-swap + z-normalise them (Interface.cc:760-776: every value is
+    // (x - mean[j]) * inv_std[j] with the NOISY statistics, targets included).  The conversion is what the
+    // epoch of the executable was bound by once the device ran at 855 k frames/s, so it is spread over the
+    // host cores; each frame is converted by exactly one thread with the same two fp32 operations, so the
+    // result does not depend on the thread count.  The staging buffer is kept between chunks (a fresh
+    // 100 MB vector per chunk costs more in page faults than the conversion itself).
+    auto load = [&](FILE *fp, int ncol, auto ensure_out, int &first_sent) {
         const size_t row_bytes = (size_t)(ncol + 2) * 4;
-        std::vector<unsigned char> raw(row_bytes * frames);
+        if (raw_.size() < row_bytes * frames) raw_.resize(row_bytes * frames);
         if (fseek(fp, kPfileHeaderBytes + (long)st * (long)row_bytes, SEEK_SET) != 0)
             throw IoError(format("pfile cannot fseek to chunk %d.", index));
-        if (fread(raw.data(), row_bytes, frames, fp) != (size_t)frames)
+        if (fread(raw_.data(), row_bytes, frames, fp) != (size_t)frames)
             throw IoError(format("pfile is too short for chunk %d.", index));
-        first_sent = frames > 0 ? be_int(raw.data()) : 0;
-        vals.resize((size_t)frames * ncol);
+        first_sent = frames > 0 ? be_int(raw_.data()) : 0;
+        const unsigned char *rawp = raw_.data();
+        float *out = ensure_out((size_t)frames * ncol);
+        const float *mean = mean_.data(), *istd = dVar_.data();
+#pragma omp parallel for schedule(static) num_threads(io_threads_)
         for (int f = 0; f < frames; f++) {
-            const unsigned char *src = raw.data() + f * row_bytes + 8;
-            float *dst = vals.data() + (size_t)f * ncol;
-            for (int j = 0; j < ncol; j++) {
-                float v = be_float(src + 4 * j);
-                v -= mean_[j % dim];
-                v *= dVar_[j % dim];
-                dst[j] = v;
+            const unsigned char *src = rawp + f * row_bytes + 8;
+            float *dst = out + (size_t)f * ncol;
+            for (int j0 = 0; j0 < ncol; j0 += dim) {  // ncol is a multiple of dim for every pfile the trainer reads
+                const int jn = ncol - j0 < dim ? ncol - j0 : dim;
+                for (int j = 0; j < jn; j++) {
+                    float v = be_float(src + 4 * (j0 + j));
+                    v -= mean[j];
+                    v *= istd[j];
+                    dst[j0 + j] = v;
+                }
             }
         }
     };
@@ -449,13 +501,19 @@ int Interface::read_chunk(const ChunkPlan &plan, int index, bool shuffle, bool e
     if (expand) {
         want_expanded_buffers();
         std::vector<float> feat, targ;
-        load(fp_data, dim, feat, sent0);
+        auto into = [](std::vector<float> &v) {
+            return [&v](size_t n) {
+                v.resize(n);
+                return v.data();
+            };
+        };
+        load(fp_data, dim, into(feat), sent0);
         float *in0 = p.indata[0];
         walk(sent0, [&](int s, int f) {
             if (s < samples)
                 memcpy(in0 + (size_t)order[s] * K0, feat.data() + (size_t)f * dim, (size_t)ctx * dim * sizeof(float));
         });
-        load(fp_targ, D, targ, sent0);
+        load(fp_targ, D, into(targ), sent0);
         float *tg0 = p.targ[0];
         walk(sent0, [&](int s, int f) {
             if (s < samples)
@@ -464,15 +522,18 @@ int Interface::read_chunk(const ChunkPlan &plan, int index, bool shuffle, bool e
     } else {
         // frame-stream form: keep the normalised frames, record where each row's window starts
         const int fi = fr_fill_;
-        load(fp_data, dim, fr_in_[fi], sent0);
-        load(fp_targ, D, fr_targ_[fi], sent0);
-        fr_first_[fi].assign(samples, 0);
-        int *first = fr_first_[fi].data();
+        auto into = [this](HostBuf &b) {
+            return [this, &b](size_t n) { return static_cast<float *>(ensure(b, n * sizeof(float))); };
+        };
+        load(fp_data, dim, into(fr_in_[fi]), sent0);
+        load(fp_targ, D, into(fr_targ_[fi]), sent0);
+        int *first = static_cast<int *>(ensure(fr_first_[fi], (size_t)(samples > 0 ? samples : 1) * sizeof(int)));
+        memset(first, 0, (size_t)samples * sizeof(int));
         walk(sent0, [&](int s, int f) {
             if (s < samples) first[order[s]] = f;
         });
-        para->frames_in[0] = fr_in_[fi].data();
-        para->frames_targ[0] = fr_targ_[fi].data();
+        para->frames_in[0] = static_cast<float *>(fr_in_[fi].p);
+        para->frames_targ[0] = static_cast<float *>(fr_targ_[fi].p);
         para->first_frame[0] = first;
         para->chunk_frames[0] = frames;
     }

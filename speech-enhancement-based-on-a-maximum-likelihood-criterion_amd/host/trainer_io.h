@@ -74,6 +74,11 @@ class Interface {
     void want_expanded_buffers();
     // call after handing slot 0 of the frame-stream buffers to the consumer (pointer swap 0<->1)
     void frames_swapped() { fr_fill_ ^= 1; }
+    // allocator of the frame-stream chunk buffers (default malloc/free); set before the first Readchunk_frames
+    void set_buffer_allocator(void *(*alloc)(size_t), void (*release)(void *)) {
+        buf_alloc_ = alloc;
+        buf_free_ = release;
+    }
     void GetRandIndex(int *vec, int len);
     void logf(const char *fmt, ...);
 
@@ -102,10 +107,21 @@ class Interface {
 
     FILE *fp_data = nullptr, *fp_targ = nullptr, *fp_out = nullptr;
     std::vector<float> mean_, dVar_;
-    std::vector<float> buf_in_[2], buf_targ_[2], fr_in_[2], fr_targ_[2];
-    std::vector<int> fr_first_[2];
+    std::vector<float> buf_in_[2], buf_targ_[2];
+    // frame-stream chunk buffers: grow-only, allocated through a pluggable allocator so that the trainer can
+    // hand out page-locked memory (pageable memory made the per-chunk upload the slowest host step)
+    struct HostBuf {
+        void *p = nullptr;
+        size_t bytes = 0;
+    };
+    HostBuf fr_in_[2], fr_targ_[2], fr_first_[2];
+    void *(*buf_alloc_)(size_t) = nullptr;
+    void (*buf_free_)(void *) = nullptr;
+    void *ensure(HostBuf &b, size_t bytes);
     bool expanded_ready_ = false;
     int fr_fill_ = 0;  // which frame-stream buffer the next Readchunk_frames fills
+    std::vector<unsigned char> raw_;  // fread staging, kept between chunks
+    int io_threads_ = 1;              // threads of the byte-swap + normalise loop (MLGGD_IO_THREADS, default: usable CPUs, max 16)
     std::vector<std::vector<float>> w_, b_;
 };
 

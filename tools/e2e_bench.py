@@ -35,3 +35,6 @@ for mode, env in (("frame-stream (device gather)", {}), ("host expansion (refere
     cv = [l for l in log.splitlines() if l.startswith("CV")]
     print("%-34s %7.2f s wall for %d training samples + CV  ->  %8.0f frames/s end to end   | %s" %
           (mode, dt, samples, samples / dt, " ; ".join(cv)), flush=True)
+    for l in r.stderr.splitlines():
+        if l.startswith("[timing]"):
+            print("      " + l, flush=True)
