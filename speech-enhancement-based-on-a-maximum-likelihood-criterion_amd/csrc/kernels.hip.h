@@ -291,9 +291,13 @@ __device__ __forceinline__ void dx_body(const DxArgs &A, const int bid, float *s
     const int r8 = lane >> 3, c4 = lane & 7;      // dEdXt staging: 8 lanes per row, 8 rows per instruction
     const int voD = (r8 * Bp + b0 + 4 * c4) * 4;
     float *wdst = wb + wr0 * DX_LDW + 4 * wc4;
-    float *ddst = db + r8 * 32 + 4 * c4;
+    // rows of the dEdXt piece are stored with bits 0 and 1 of the row number swapped: the two half-waves of a
+    // fragment read (rows 4j and 4j+2, or 4j+1 and 4j+3) then sit 32 words apart, in different bank halves
+    // (stored in natural order they were 64 words apart = the same banks: a 2-way conflict on every read,
+    // 20 % of this kernel's LDS cycles in profiles/r01_sq_counters.txt)
+    float *ddst = db + ((r8 & ~3) | ((r8 & 1) << 1) | ((r8 >> 1) & 1)) * 32 + 4 * c4;
     const float *ard = wb + i * DX_LDW + 2 * h;
-    const float *brd = db + 2 * h * 32 + i;
+    const float *brd = db + h * 32 + i;
 
     f32x16 acc;
 #pragma unroll
@@ -326,7 +330,7 @@ __device__ __forceinline__ void dx_body(const DxArgs &A, const int bid, float *s
             if (j < (CNT)) {                                                               \
                 const float2 av = *reinterpret_cast<const float2 *>(ard + 4 * j);          \
                 acc = mfma32(av.x, brd[(4 * j) * 32], acc);                                \
-                acc = mfma32(av.y, brd[(4 * j + 1) * 32], acc);                            \
+                acc = mfma32(av.y, brd[(4 * j + 2) * 32], acc);                            \
             }                                                                              \
         }                                                                                  \
         __builtin_amdgcn_wave_barrier();                                                   \
