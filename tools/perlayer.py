@@ -15,7 +15,8 @@ for cls, layers in (("transpose", (0,)), ("fwd", (1, 2, 3, 4)), ("loss", (0,)), 
     for l in layers:
         eng.profile_select(cls, l, 4096); eng.train_resident(0, NB * B); us, n = eng.profile_read()
         if n:
-            f, by = eng.kernel_work(cls, l)
+            # one dW launch covers all layers on a single GPU: its work is the sum over the layers
+            f, by = eng.kernel_work(cls, 0 if (cls == "dw" and eng.dw_launches_per_step() == 1) else l)
             print("%-10s layer %d: %7.2f us  (%d launches)%s" % (cls, l, us, n,
                   "  %.1f TFLOP/s  %.0f GB/s alg" % (f / us / 1e6, by / us / 1e3) if f else ""))
             tot += us * n / NB
