@@ -18,8 +18,14 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def pkg():
-    """The product package (directory name has hyphens, so import by string)."""
-    return importlib.import_module(PKG_NAME)
+    """The product package (directory name has hyphens, so import by string).  If the in-tree build is
+    missing (a checkout without the git-ignored .so files) the test session builds it first -- the product
+    itself never does that: load() fails loudly when libmlggd.so is absent."""
+    mod = importlib.import_module(PKG_NAME)
+    if not os.path.exists(mod.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    return mod
 
 
 @pytest.fixture(scope="session")
