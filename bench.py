@@ -97,6 +97,11 @@ def main():
             assert got == m
             done += m
 
+    # clock / power-state ramp: the GPU needs tens of milliseconds under load to reach its steady clocks, a
+    # short --warmup does not get there (100 timed steps after 10 warm-up steps read 8 % low).  Untimed.
+    # A fixed step count, not a time: data-parallel ranks must all run the same number of steps.
+    run_steps(512)
+    eng.sync()
     run_steps(args.warmup)
     eng.sync()
     if not args.no_kernel_timing:
