@@ -594,9 +594,13 @@ __global__ __launch_bounds__(256) void k_dw(const float *__restrict__ Yrow, int 
 // 64x64 tiles, <= 2 workgroups per CU, each walking tiles t = blockIdx.x, += gridDim.x.
 // A "unit" is one 64-frame slice of a tile's two operand tiles (32 KB of LDS, two buffers).
 // While unit u runs on the MFMA pipe, the 16-byte loads of unit u+1 (to registers) and 1/H
-// of the NEXT tile's W/delta tiles (to a second register set) are in flight, so HBM streams
-// continuously instead of in per-workgroup bursts (stage -> MFMA -> store lock-step of
-// k_dw: profiles/r01_phase_stamps.txt).  Every global access is an UNCONDITIONAL buffer
+// of the NEXT tile's W/delta tiles (to a second register set) are in flight, so memory streams
+// continuously instead of in per-workgroup bursts (the stage -> MFMA -> store lock-step of k_dw).
+// What bounds it (profiles/r01_sq_counters.txt, r01_vmem_rate.txt): its memory-
+// pipeline time (118 MB of stores at 27 ns per dwordx4 store and CU, 351 MB of loads at 7 ns) and its
+// MFMA time add up instead of overlapping; the per-unit loads are therefore interleaved with the
+// MFMAs in the instruction stream (DWP_INTERLEAVE), the only placement that overlaps on this chip
+// (tools/overlap_probe.hip).  Every global access is an UNCONDITIONAL buffer
 // load/store whose out-of-range cases (pad rows k >= K, no next tile) are expressed through the
 // offset / an empty descriptor and dropped by the hardware range check: with no branch
 // around any memory instruction the compiler's s_waitcnt vmcnt(N) before the LDS write
