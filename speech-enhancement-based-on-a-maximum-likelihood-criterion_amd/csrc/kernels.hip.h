@@ -1062,8 +1062,9 @@ __device__ __forceinline__ void loss_err_body(const LossErrArgs &A, const int bi
 // Yt[0] is free once forward_1 has run): the loss kernel occupies 36 of 256 CUs, so the staging
 // blocks ride along on the idle ones instead of costing a launch of their own.
 __global__ __launch_bounds__(256) void k_loss_err(LossErrArgs A, int n_loss, StageArgs G) {
-    if ((int)blockIdx.x < n_loss) loss_err_body(A, (int)blockIdx.x);
-    else transpose_in_body(G, (int)blockIdx.x - n_loss);
+    const int n_stage = (int)gridDim.x - n_loss;  // staging blocks first: they are the longer ones
+    if ((int)blockIdx.x >= n_stage) loss_err_body(A, (int)blockIdx.x - n_stage);
+    else transpose_in_body(G, (int)blockIdx.x);
 }
 
 // Per-dimension sum over the minibatch of |e|^beta in the reference's order (kernSumcol,
@@ -1237,8 +1238,9 @@ __device__ __forceinline__ void loss_norm_body(const LossNormArgs &A, const int 
     }
 }
 __global__ __launch_bounds__(256) void k_loss_norm(LossNormArgs A, int n_loss, StageArgs G) {
-    if ((int)blockIdx.x < n_loss) loss_norm_body(A, (int)blockIdx.x);
-    else transpose_in_body(G, (int)blockIdx.x - n_loss);
+    const int n_stage = (int)gridDim.x - n_loss;  // staging blocks first: they are the longer ones
+    if ((int)blockIdx.x >= n_stage) loss_norm_body(A, (int)blockIdx.x - n_stage);
+    else transpose_in_body(G, (int)blockIdx.x);
 }
 
 // Forward-only output (cv_bunch_single, BP_GPU.cu:442-512): out[b][d] = bias + sum_s slab,
