@@ -148,6 +148,10 @@ struct mlggd_engine {
     bool fake_world = false;  // test hook: `world` identical ranks emulated with device copies, no communicator
     float *Yall[MLGGD_MAXLAYER] = {0}, *dEdXall[MLGGD_MAXLAYER] = {0};
     hipEvent_t ev_ready = nullptr, ev_gathered = nullptr;
+    // fine-grained factor exchange (few ranks: cheap collectives, few links): every factor is sent as soon as it
+    // exists, and ev_layer[l] marks the moment both factors of layer l have arrived
+    int dp_fine = 1;
+    hipEvent_t ev_layer[MLGGD_MAXLAYER] = {0};
     RcclComm comm = nullptr;
     hipEvent_t ev_grad[MLGGD_MAXLAYER] = {0}, ev_red[MLGGD_MAXLAYER] = {0}, ev_bias = nullptr, ev_bias_red = nullptr;
 
@@ -378,7 +382,7 @@ static int run_dropout(mlggd_engine *e, int layer, const float *chunk_rows) {
 static int gather_begin(mlggd_engine *e);
 static int gather_end(mlggd_engine *e);
 static int gather_one(mlggd_engine *e, const float *src, float *dst, size_t count);
-enum { GATHER_INPUT = 1, GATHER_HIDDEN = 2 };  // data-parallel factor exchange issued from inside the forward pass
+enum { GATHER_INPUT = 1, GATHER_HIDDEN = 2, GATHER_HIDDEN_EACH = 4 };  // data-parallel factor exchange issued from inside the forward pass
 
 static int run_forward(mlggd_engine *e, const Bunch &bn, int frames, bool training, bool prestaged = false,
                        int gather_flags = 0) {
@@ -431,6 +435,11 @@ static int run_forward(mlggd_engine *e, const Bunch &bn, int frames, bool traini
             hipLaunchKernelGGL(k_scale, dim3(1024), dim3(256), 0, e->stream, e->W[l], (size_t)Kp * Np, 1.0f / keep);
         }
         if (drop && l != e->L - 1) CHK(run_dropout(e, l, nullptr));
+        if ((gather_flags & GATHER_HIDDEN_EACH) && l < e->L - 1) {  // each hidden layer's activations at once
+            CHK(gather_begin(e));
+            CHK(gather_one(e, e->Y[l], e->Yall[l], (size_t)e->Bp * e->lsp[l]));
+            CHK(gather_end(e));
+        }
         if ((gather_flags & GATHER_HIDDEN) && l == e->L - 2) {  // all hidden activations exist: send them
             CHK(gather_begin(e));                               // beside the output layer, the loss and dX
             for (int g = 1; g < e->L - 1; g++) CHK(gather_one(e, e->Y[g], e->Yall[g], (size_t)e->Bp * e->lsp[g]));
@@ -538,6 +547,9 @@ static int gather_alloc(mlggd_engine *e) {
     }
     HIPCHK(hipEventCreateWithFlags(&e->ev_ready, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&e->ev_gathered, hipEventDisableTiming));
+    for (int l = 1; l < e->L; l++) HIPCHK(hipEventCreateWithFlags(&e->ev_layer[l], hipEventDisableTiming));
+    if (const char *v = getenv("MLGGD_DP_FINE")) e->dp_fine = atoi(v);
+    else e->dp_fine = e->world <= 5 ? 1 : 0;
     return MLGGD_OK;
 }
 // one rank's block -> every rank's slot r of dst (on the communication stream)
@@ -625,10 +637,10 @@ static DwpJobs dwp_jobs_shard(mlggd_engine *e, float nf, int r, bool with_bias_o
     J.total = end;
     return J;
 }
-static DwpJobs dwp_jobs_global(mlggd_engine *e, float nf) {
-    DwpJobs J = dwp_jobs(e, e->L - 1, 1, e->Yall[0], nf);
+static DwpJobs dwp_jobs_global(mlggd_engine *e, float nf, int lhi, int llo) {
+    DwpJobs J = dwp_jobs(e, lhi, llo, e->Yall[0], nf);
     for (int j = 0; j < J.njobs; j++) {
-        const int l = e->L - 1 - j;
+        const int l = lhi - j;
         J.job[j].Yrow = e->Yall[l - 1];
         J.job[j].dEdX = e->dEdXall[l];
         J.job[j].B = e->world * e->Bp;
@@ -674,7 +686,11 @@ static int run_step(mlggd_engine *e, const Bunch &bn, bool prestaged = false, co
     // loss statistic uses the same communicator, and collectives of one communicator run one after the other
     // whatever stream they are on -- it must not queue behind megabytes of factors (the input rows, sent at
     // the start of the step, have long arrived by then).
-    CHK(run_forward(e, bn, B, true, prestaged, gather ? (GATHER_INPUT | (ML != 1 ? GATHER_HIDDEN : 0)) : 0));
+    // fine: replicated update on few ranks -- send every factor as soon as it exists (the links are the
+    // bottleneck there, so they should never idle) and start the upper layers' dW while dEdX_1 still travels
+    const bool fine = gather && e->dp_mode == 1 && e->dp_fine != 0;
+    CHK(run_forward(e, bn, B, true, prestaged,
+                    gather ? (GATHER_INPUT | (ML != 1 ? (fine ? GATHER_HIDDEN_EACH : GATHER_HIDDEN) : 0)) : 0));
     const float *in_rows = bunch_rows(e, bn);  // after run_forward: it may have switched in_bunch
     // input of the next step: Yt[0] is free from here on (forward_1 has been enqueued); frame-stream
     // rows go to the OTHER in_bunch buffer because this step's dW(1) still reads the current one
@@ -735,7 +751,12 @@ static int run_step(mlggd_engine *e, const Bunch &bn, bool prestaged = false, co
     int pending_hi = L - 1;  // gather mode: dEdX_l for l in [l .. pending_hi] are final and not yet sent
     for (int l = L - 1; l >= 1; l--) {
         const int Kp = e->lsp[l - 1], Np = e->lsp[l];
-        if (gather && l <= 2) {  // two groups: everything down to dEdX_2 beside dX_2, dEdX_1 at the end
+        if (fine) {  // dEdX_l is final here (loss or dX_{l+1} has been enqueued): send it, layer l is then complete
+            CHK(gather_begin(e));
+            CHK(gather_one(e, e->dEdX[l], e->dEdXall[l], (size_t)Bp * e->lsp[l]));
+            CHK(gather_end(e));
+            HIPCHK(hipEventRecord(e->ev_layer[l], e->comm_stream));
+        } else if (gather && l <= 2) {  // two groups: everything down to dEdX_2 beside dX_2, dEdX_1 at the end
             CHK(gather_begin(e));
             for (int g = pending_hi; g >= l; g--) CHK(gather_one(e, e->dEdX[g], e->dEdXall[g], (size_t)Bp * e->lsp[g]));
             CHK(gather_end(e));
@@ -809,11 +830,23 @@ static int run_step(mlggd_engine *e, const Bunch &bn, bool prestaged = false, co
                 e->ev_W_pending[l] = true;
             }
         }
+    } else if (fine) {
+        // two launches: layers L-1..2 as soon as dEdX_2 has arrived (after dX_2 in stream order, which still reads
+        // the old W_2), layer 1 when dEdX_1 has
+        const int units = e->world * Bp / 64;
+        if (L - 1 >= 2) {
+            HIPCHK(hipStreamWaitEvent(dws, e->ev_layer[2], 0));
+            ProfScope ps(e, KC_DW, L - 1, dws);
+            CHK(launch_dwp(e, dwp_jobs_global(e, nf, L - 1, 2), true, dws, L - 1, units));
+        }
+        HIPCHK(hipStreamWaitEvent(dws, e->ev_layer[1], 0));
+        ProfScope ps(e, KC_DW, 1, dws);
+        CHK(launch_dwp(e, dwp_jobs_global(e, nf, 1, 1), true, dws, 1, units));
     } else if (gather) {
         HIPCHK(hipEventRecord(e->ev_gathered, e->comm_stream));
         HIPCHK(hipStreamWaitEvent(dws, e->ev_gathered, 0));
         ProfScope ps(e, KC_DW, 1, dws);
-        CHK(launch_dwp(e, dwp_jobs_global(e, nf), true, dws, 1, e->world * Bp / 64));
+        CHK(launch_dwp(e, dwp_jobs_global(e, nf, L - 1, 1), true, dws, 1, e->world * Bp / 64));
     } else if (merged) {
         ProfScope ps(e, KC_DW, 1, dws);
         CHK(launch_dwp(e, dwp_jobs(e, L - 1, 1, in_rows, nf), true, dws, 1));
@@ -969,8 +1002,10 @@ int mlggd_destroy(mlggd_handle e) {
         if (e->ev_grad[l]) hipEventDestroy(e->ev_grad[l]);
         if (e->ev_red[l]) hipEventDestroy(e->ev_red[l]);
     }
-    for (int l = 0; l < MLGGD_MAXLAYER; l++)
+    for (int l = 0; l < MLGGD_MAXLAYER; l++) {
         if (e->ev_W[l]) hipEventDestroy(e->ev_W[l]);
+        if (e->ev_layer[l]) hipEventDestroy(e->ev_layer[l]);
+    }
     if (e->ev_dw_done) hipEventDestroy(e->ev_dw_done);
     if (e->ev_ready) hipEventDestroy(e->ev_ready);
     if (e->ev_gathered) hipEventDestroy(e->ev_gathered);
@@ -1618,7 +1653,8 @@ int mlggd_dw_launches_per_step(mlggd_handle e, int *launches) {
     if (!e || !launches) return fail(MLGGD_ERR_ARG, "NULL argument");
     const bool dp = e->comm != nullptr || e->fake_world;
     const bool merged = (!dp && !e->two_streams && e->dw_merge && dwp_usable(e)) || (dp && e->dp_mode >= 1);
-    *launches = merged ? 1 : e->L - 1;
+    const bool fine = dp && e->dp_mode == 1 && e->dp_fine != 0 && e->L - 1 >= 2;
+    *launches = fine ? 2 : merged ? 1 : e->L - 1;
     return MLGGD_OK;
 }
 
