@@ -70,8 +70,11 @@ static int usable_cpus() {
 }
 
 Interface::Interface() : para(new WorkPara) {
+    // a handful of threads is enough (the loop is memory-bound) and idle OpenMP workers must not spin next
+    // to the thread that feeds the GPU
     io_threads_ = usable_cpus();
-    if (io_threads_ > 16) io_threads_ = 16;
+    if (io_threads_ > 4) io_threads_ = 4;
+    setenv("OMP_WAIT_POLICY", "passive", 0);
     if (const char *v = getenv("MLGGD_IO_THREADS")) io_threads_ = atoi(v) > 0 ? atoi(v) : 1;
 }
 

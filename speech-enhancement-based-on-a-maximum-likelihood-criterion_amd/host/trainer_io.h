@@ -121,7 +121,7 @@ class Interface {
     bool expanded_ready_ = false;
     int fr_fill_ = 0;  // which frame-stream buffer the next Readchunk_frames fills
     std::vector<unsigned char> raw_;  // fread staging, kept between chunks
-    int io_threads_ = 1;              // threads of the byte-swap + normalise loop (MLGGD_IO_THREADS, default: usable CPUs, max 16)
+    int io_threads_ = 1;              // threads of the byte-swap + normalise loop (MLGGD_IO_THREADS, default: usable CPUs, max 4)
     std::vector<std::vector<float>> w_, b_;
 };
 
