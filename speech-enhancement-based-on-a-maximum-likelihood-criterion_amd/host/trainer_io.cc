@@ -70,11 +70,11 @@ static int usable_cpus() {
 }
 
 Interface::Interface() : para(new WorkPara) {
-    // a handful of threads is enough (the loop is memory-bound) and idle OpenMP workers must not spin next
-    // to the thread that feeds the GPU
+    // a handful of threads is enough (the loop is memory-bound), and idle OpenMP workers spin for a while
+    // after every parallel region, next to the thread that feeds the GPU (OMP_WAIT_POLICY=passive in the
+    // environment avoids that; it is read when libgomp loads, so it cannot be set from here)
     io_threads_ = usable_cpus();
     if (io_threads_ > 4) io_threads_ = 4;
-    setenv("OMP_WAIT_POLICY", "passive", 0);
     if (const char *v = getenv("MLGGD_IO_THREADS")) io_threads_ = atoi(v) > 0 ? atoi(v) : 1;
 }
 
