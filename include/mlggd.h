@@ -107,6 +107,10 @@ int mlggd_load_frames(mlggd_handle h, int n_frames, int fea_context, const float
                       int n_samples, const int32_t *first_frame, int targ_offset);
 int mlggd_train_frames(mlggd_handle h, int n_frames, int fea_context, const float *feat, const float *targ,
                        int n_samples, const int32_t *first_frame, int targ_offset, int *bunches_trained);
+/* mlggd_train_frames without the final wait: returns when the chunk is on the device and its steps are enqueued;
+ * the next chunk's upload then overlaps them (two device buffer sets).  mlggd_sync() waits. */
+int mlggd_train_frames_async(mlggd_handle h, int n_frames, int fea_context, const float *feat, const float *targ,
+                       int n_samples, const int32_t *first_frame, int targ_offset, int *bunches_trained);
 int mlggd_cv_all_frames(mlggd_handle h, int n_frames, int fea_context, const float *feat, const float *targ,
                         int n_samples, const int32_t *first_frame, int targ_offset, float *sqerr, float *abserr,
                         float *loglik);

@@ -46,7 +46,7 @@ EXPORTS = [
     "mlggd_profile_select", "mlggd_profile_stride", "mlggd_profile_read", "mlggd_profile_overhead",
     "mlggd_kernel_work", "mlggd_dw_launches_per_step", "mlggd_dp_mode", "mlggd_debug_fake_world",
     "mlggd_debug_stamp_select", "mlggd_debug_stamp_read",
-    "mlggd_load_frames", "mlggd_train_frames", "mlggd_cv_all_frames", "mlggd_forward_frames",
+    "mlggd_load_frames", "mlggd_train_frames", "mlggd_train_frames_async", "mlggd_cv_all_frames", "mlggd_forward_frames",
     "mlggd_alloc_pinned", "mlggd_free_pinned",
 ]
 
@@ -110,6 +110,7 @@ def load():
     _ip = C.POINTER(C.c_int32)
     L.mlggd_load_frames.argtypes = [C.c_void_p, C.c_int, C.c_int, _fp, _fp, C.c_int, _ip, C.c_int]
     L.mlggd_train_frames.argtypes = [C.c_void_p, C.c_int, C.c_int, _fp, _fp, C.c_int, _ip, C.c_int, C.POINTER(C.c_int)]
+    L.mlggd_train_frames_async.argtypes = L.mlggd_train_frames.argtypes
     L.mlggd_cv_all_frames.argtypes = [C.c_void_p, C.c_int, C.c_int, _fp, _fp, C.c_int, _ip, C.c_int, _fp, _fp, _fp]
     L.mlggd_forward_frames.argtypes = [C.c_void_p, C.c_int, C.c_int, _fp, C.c_int, _ip, _fp]
     L.mlggd_alloc_pinned.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]

@@ -131,6 +131,17 @@ struct mlggd_engine {
     float *in_bunch_buf[2] = {nullptr, nullptr};  // in_bunch alternates between them when bunches are staged ahead
     int *first_frame = nullptr;
     size_t raw_cap = 0, first_cap = 0;
+    // Frame-stream chunks ping-pong between two device buffer sets: the next chunk is uploaded on copy_stream
+    // while the kernels of the current one are still running (raw_feat / raw_targ / first_frame / *_cap above
+    // always describe the CURRENT set).
+    struct RawSet {
+        float *feat = nullptr, *targ = nullptr;
+        int *first = nullptr;
+        size_t raw_cap = 0, first_cap = 0;
+        hipEvent_t last_use = nullptr;  // recorded on the main stream after the last kernel that reads the set
+    } raw[2];
+    int raw_cur = 0;
+    hipStream_t copy_stream = nullptr;
     bool indexed = false;
     int fdim = 0, toff = 0, raw_frames = 0;
     unsigned step_counter = 0;
@@ -994,9 +1005,14 @@ int mlggd_destroy(mlggd_handle e) {
     if (e->chunk_in) hipFree(e->chunk_in);
     if (e->chunk_targ) hipFree(e->chunk_targ);
     if (e->chunk_out) hipFree(e->chunk_out);
-    if (e->raw_feat) hipFree(e->raw_feat);
-    if (e->raw_targ) hipFree(e->raw_targ);
-    if (e->first_frame) hipFree(e->first_frame);
+    if (e->copy_stream) hipStreamSynchronize(e->copy_stream);
+    for (auto &r : e->raw) {
+        if (r.feat) hipFree(r.feat);
+        if (r.targ) hipFree(r.targ);
+        if (r.first) hipFree(r.first);
+        if (r.last_use) hipEventDestroy(r.last_use);
+    }
+    if (e->copy_stream) hipStreamDestroy(e->copy_stream);
     for (hipEvent_t ev : e->prof_ev) hipEventDestroy(ev);
     for (int l = 0; l < MLGGD_MAXLAYER; l++) {
         if (e->ev_grad[l]) hipEventDestroy(e->ev_grad[l]);
@@ -1128,35 +1144,50 @@ int mlggd_load_frames(mlggd_handle e, int n_frames, int fea_context, const float
             return fail(MLGGD_ERR_ARG, "sample %d: window [%d,%d) outside the %d uploaded frames", s, first_frame[s],
                         first_frame[s] + fea_context, n_frames);
     HIPCHK(hipSetDevice(e->device));
+    if (!e->copy_stream) {
+        HIPCHK(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+        for (auto &r : e->raw) HIPCHK(hipEventCreateWithFlags(&r.last_use, hipEventDisableTiming));
+    }
+    // the set that is NOT current: its last reader (two chunks ago) has finished or is about to; wait for it
+    // on the host before touching the allocation, then copy beside whatever the main stream is still running
+    mlggd_engine::RawSet &r = e->raw[e->raw_cur ^ 1];
+    HIPCHK(hipEventSynchronize(r.last_use));
     const size_t need = (size_t)n_frames + fea_context + 8;
-    if (need > e->raw_cap) {
-        if (e->raw_feat) hipFree(e->raw_feat);
-        if (e->raw_targ) hipFree(e->raw_targ);
-        e->raw_feat = e->raw_targ = nullptr;
-        e->raw_cap = 0;
-        HIPCHK(hipMalloc((void **)&e->raw_feat, need * fdim * sizeof(float)));
-        HIPCHK(hipMalloc((void **)&e->raw_targ, need * e->D * sizeof(float)));
-        HIPCHK(hipMemsetAsync(e->raw_feat, 0, need * fdim * sizeof(float), e->stream));
-        HIPCHK(hipMemsetAsync(e->raw_targ, 0, need * e->D * sizeof(float), e->stream));
-        e->raw_cap = need;
+    if (need > r.raw_cap) {
+        if (r.feat) hipFree(r.feat);
+        if (r.targ) hipFree(r.targ);
+        r.feat = r.targ = nullptr;
+        r.raw_cap = 0;
+        HIPCHK(hipMalloc((void **)&r.feat, need * fdim * sizeof(float)));
+        HIPCHK(hipMalloc((void **)&r.targ, need * e->D * sizeof(float)));
+        HIPCHK(hipMemsetAsync(r.feat, 0, need * fdim * sizeof(float), e->copy_stream));
+        HIPCHK(hipMemsetAsync(r.targ, 0, need * e->D * sizeof(float), e->copy_stream));
+        r.raw_cap = need;
     }
     const size_t need_s = (size_t)n_samples + e->Bp + 32;
-    if (need_s > e->first_cap) {
-        if (e->first_frame) hipFree(e->first_frame);
-        e->first_frame = nullptr;
-        e->first_cap = 0;
-        HIPCHK(hipMalloc((void **)&e->first_frame, need_s * sizeof(int)));
-        HIPCHK(hipMemsetAsync(e->first_frame, 0, need_s * sizeof(int), e->stream));
-        e->first_cap = need_s;
+    if (need_s > r.first_cap) {
+        if (r.first) hipFree(r.first);
+        r.first = nullptr;
+        r.first_cap = 0;
+        HIPCHK(hipMalloc((void **)&r.first, need_s * sizeof(int)));
+        HIPCHK(hipMemsetAsync(r.first, 0, need_s * sizeof(int), e->copy_stream));
+        r.first_cap = need_s;
     }
     if (n_frames > 0) {
-        HIPCHK(hipMemcpyAsync(e->raw_feat, feat, (size_t)n_frames * fdim * 4, hipMemcpyHostToDevice, e->stream));
-        if (targ)
-            HIPCHK(hipMemcpyAsync(e->raw_targ, targ, (size_t)n_frames * e->D * 4, hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(r.feat, feat, (size_t)n_frames * fdim * 4, hipMemcpyHostToDevice, e->copy_stream));
+        if (targ) HIPCHK(hipMemcpyAsync(r.targ, targ, (size_t)n_frames * e->D * 4, hipMemcpyHostToDevice, e->copy_stream));
     }
     if (n_samples > 0)
-        HIPCHK(hipMemcpyAsync(e->first_frame, first_frame, (size_t)n_samples * sizeof(int), hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
+        HIPCHK(hipMemcpyAsync(r.first, first_frame, (size_t)n_samples * sizeof(int), hipMemcpyHostToDevice, e->copy_stream));
+    // the caller's buffers are free when this returns; kernels enqueued from now on see the data (the host has
+    // observed the copies complete)
+    HIPCHK(hipStreamSynchronize(e->copy_stream));
+    e->raw_cur ^= 1;
+    e->raw_feat = r.feat;
+    e->raw_targ = r.targ;
+    e->first_frame = r.first;
+    e->raw_cap = r.raw_cap;
+    e->first_cap = r.first_cap;
     e->chunk_frames = n_samples;
     e->raw_frames = n_frames;
     e->indexed = true;
@@ -1171,6 +1202,16 @@ int mlggd_train_frames(mlggd_handle e, int n_frames, int fea_context, const floa
     CHK(mlggd_load_frames(e, n_frames, fea_context, feat, targ, n_samples, first_frame, targ_offset));
     CHK(mlggd_train_resident(e, 0, n_samples, bunches_trained));
     return mlggd_sync(e);
+}
+
+// The same without the final wait: returns once the chunk is on the device (the caller's buffers are free) and
+// its steps are enqueued.  The next call uploads the next chunk into the other device buffer set while these
+// steps still run; mlggd_sync / mlggd_get_weights / any CV call waits for them.
+int mlggd_train_frames_async(mlggd_handle e, int n_frames, int fea_context, const float *feat, const float *targ,
+                             int n_samples, const int32_t *first_frame, int targ_offset, int *bunches_trained) {
+    if (n_samples > 0 && !targ) return fail(MLGGD_ERR_ARG, "targ is NULL");
+    CHK(mlggd_load_frames(e, n_frames, fea_context, feat, targ, n_samples, first_frame, targ_offset));
+    return mlggd_train_resident(e, 0, n_samples, bunches_trained);
 }
 
 // Pinned host memory for the caller's chunk buffers (faster, truly asynchronous H2D).
@@ -1203,6 +1244,8 @@ int mlggd_train_resident(mlggd_handle e, int first_frame, int n_frames, int *bun
         trained++;
     }
     HIPCHK(hipEventRecord(e->ev_t1, e->stream));
+    if (e->indexed && e->copy_stream)  // the next-but-one upload reuses this buffer set: it waits for this point
+        HIPCHK(hipEventRecord(e->raw[e->raw_cur].last_use, e->stream));
     e->last_steps = trained;
     e->timing_valid = true;
     if (bunches_trained) *bunches_trained = trained;

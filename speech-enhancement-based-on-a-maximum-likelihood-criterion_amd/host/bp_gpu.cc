@@ -71,11 +71,17 @@ void BP_GPU::CrossValidAll(int n, const float *in, const float *targ, float *sqe
 void BP_GPU::cv_bunch_single(int n, const float *in, float *out) {
     check(mlggd_forward(h_, n, in, out), "mlggd_forward");
 }
+void BP_GPU::sync() { check(mlggd_sync(h_), "mlggd_sync"); }
 void BP_GPU::train_frames(int n_frames, int fea_context, const float *feat, const float *targ, int n_samples,
-                          const int *first_frame, int targ_offset) {
+                          const int *first_frame, int targ_offset, bool wait) {
     int trained = 0;
-    check(mlggd_train_frames(h_, n_frames, fea_context, feat, targ, n_samples, first_frame, targ_offset, &trained),
-          "mlggd_train_frames");
+    if (wait)
+        check(mlggd_train_frames(h_, n_frames, fea_context, feat, targ, n_samples, first_frame, targ_offset, &trained),
+              "mlggd_train_frames");
+    else
+        check(mlggd_train_frames_async(h_, n_frames, fea_context, feat, targ, n_samples, first_frame, targ_offset,
+                                       &trained),
+              "mlggd_train_frames_async");
     const int rest = n_samples - trained * bunchsize;
     if (rest > 0) printf("this bunch has only %d samples and is ignored.\n", rest);  // BP_GPU.cu:179
 }

@@ -20,8 +20,11 @@ class BP_GPU {
     void CrossValidAll(int n_frames, const float *in, const float *targ, float *sqerr, float *abserr, float *loglik);
     void cv_bunch_single(int n_frames, const float *in, float *out);
     // frame-stream chunks (not in the reference): rows gathered on the device, see mlggd_load_frames
+    // wait = false: return once the chunk is uploaded (the buffers are free) and its steps are enqueued; the next
+    // chunk's upload then overlaps them.  sync() / returnWeights / CrossValid* wait for everything.
     void train_frames(int n_frames, int fea_context, const float *feat, const float *targ, int n_samples,
-                      const int *first_frame, int targ_offset);
+                      const int *first_frame, int targ_offset, bool wait = true);
+    void sync();
     void CrossValidAll_frames(int n_frames, int fea_context, const float *feat, const float *targ, int n_samples,
                               const int *first_frame, int targ_offset, float *sqerr, float *abserr, float *loglik);
     void returnWeights(float **weights, float **bias);

@@ -212,8 +212,10 @@ int main(int argc, char *argv[]) {
                     first = loc_first.data();
                     nloc = nglob * B;
                 }
+                // no wait: the buffers are free once the chunk is on the device, and the next chunk's upload
+                // overlaps these steps (the engine keeps two device buffer sets)
                 net->train_frames(p->chunk_frames[1], p->fea_context, p->frames_in[1], p->frames_targ[1], nloc, first,
-                                  p->targ_offset);
+                                  p->targ_offset, /*wait=*/false);
             } else if (world == 1) {
                 net->train(ns, p->indata[1], p->targ[1]);
             } else {
@@ -232,6 +234,7 @@ int main(int argc, char *argv[]) {
         }
         fetch.join();
         if (!fetch_error.empty()) throw IoError(fetch_error);
+        net->sync();
         phase("training chunks", t_phase);
 
         io->logf("Total cost time: %.1f s.\n", (double)time(NULL) - t_start);  // BPtrain.cc:104-105

@@ -8,6 +8,8 @@
 #include <cstring>
 #include <thread>
 #include <sched.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 
 namespace mlggd_host {
 
@@ -78,6 +80,25 @@ Interface::Interface() : para(new WorkPara) {
     if (const char *v = getenv("MLGGD_IO_THREADS")) io_threads_ = atoi(v) > 0 ? atoi(v) : 1;
 }
 
+// read-only mapping of a pfile (nullptr if it cannot be mapped); MLGGD_MMAP=0 forces the fread path
+const unsigned char *Interface::map_file(FILE *fp) {
+    Mapping &m = fp == fp_data ? map_data_ : map_targ_;
+    if (!m.tried) {
+        m.tried = true;
+        const char *v = getenv("MLGGD_MMAP");
+        struct stat st;
+        if (!(v && atoi(v) == 0) && fstat(fileno(fp), &st) == 0 && st.st_size > 0) {
+            void *q = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fileno(fp), 0);
+            if (q != MAP_FAILED) {
+                m.base = static_cast<const unsigned char *>(q);
+                m.size = (size_t)st.st_size;
+            }
+        }
+    }
+    return m.base;
+}
+size_t Interface::map_size(FILE *fp) { return (fp == fp_data ? map_data_ : map_targ_).size; }
+
 void *Interface::ensure(HostBuf &b, size_t bytes) {
     if (b.bytes >= bytes && b.p) return b.p;
     if (b.p) (buf_free_ ? buf_free_ : free)(b.p);
@@ -89,6 +110,8 @@ void *Interface::ensure(HostBuf &b, size_t bytes) {
 }
 
 Interface::~Interface() {
+    for (Mapping *m : {&map_data_, &map_targ_})
+        if (m->base) munmap(const_cast<unsigned char *>(m->base), m->size);
     for (HostBuf *set : {fr_in_, fr_targ_, fr_first_})
         for (int i = 0; i < 2; i++)
             if (set[i].p) (buf_free_ ? buf_free_ : free)(set[i].p);
@@ -463,13 +486,23 @@ int Interface::read_chunk(const ChunkPlan &plan, int index, bool shuffle, bool e
     // 100 MB vector per chunk costs more in page faults than the conversion itself).
     auto load = [&](FILE *fp, int ncol, auto ensure_out, int &first_sent) {
         const size_t row_bytes = (size_t)(ncol + 2) * 4;
-        if (raw_.size() < row_bytes * frames) raw_.resize(row_bytes * frames);
-        if (fseek(fp, kPfileHeaderBytes + (long)st * (long)row_bytes, SEEK_SET) != 0)
-            throw IoError(format("pfile cannot fseek to chunk %d.", index));
-        if (fread(raw_.data(), row_bytes, frames, fp) != (size_t)frames)
-            throw IoError(format("pfile is too short for chunk %d.", index));
-        first_sent = frames > 0 ? be_int(raw_.data()) : 0;
-        const unsigned char *rawp = raw_.data();
+        const size_t off = (size_t)kPfileHeaderBytes + (size_t)st * row_bytes;
+        // Preferred source: the file mapped read-only -- the conversion threads then pull the rows straight out
+        // of the page cache in parallel (one thread's fread of ~100 MB per file and chunk was what the epoch of
+        // the executable waited for).  fread into a staging buffer (kept between chunks) if it cannot be mapped.
+        const unsigned char *mapped = map_file(fp);
+        const unsigned char *src0;
+        if (mapped && off + row_bytes * frames <= map_size(fp)) {
+            src0 = mapped + off;
+        } else {
+            if (raw_.size() < row_bytes * frames) raw_.resize(row_bytes * frames);
+            if (fseek(fp, (long)off, SEEK_SET) != 0) throw IoError(format("pfile cannot fseek to chunk %d.", index));
+            if (fread(raw_.data(), row_bytes, frames, fp) != (size_t)frames)
+                throw IoError(format("pfile is too short for chunk %d.", index));
+            src0 = raw_.data();
+        }
+        first_sent = frames > 0 ? be_int(src0) : 0;
+        const unsigned char *rawp = src0;
         float *out = ensure_out((size_t)frames * ncol);
         const float *mean = mean_.data(), *istd = dVar_.data();
 #pragma omp parallel for schedule(static) num_threads(io_threads_)

@@ -118,6 +118,13 @@ class Interface {
     void *(*buf_alloc_)(size_t) = nullptr;
     void (*buf_free_)(void *) = nullptr;
     void *ensure(HostBuf &b, size_t bytes);
+    struct Mapping {
+        const unsigned char *base = nullptr;
+        size_t size = 0;
+        bool tried = false;
+    } map_data_, map_targ_;
+    const unsigned char *map_file(FILE *fp);
+    size_t map_size(FILE *fp);
     bool expanded_ready_ = false;
     int fr_fill_ = 0;  // which frame-stream buffer the next Readchunk_frames fills
     std::vector<unsigned char> raw_;  // fread staging, kept between chunks
