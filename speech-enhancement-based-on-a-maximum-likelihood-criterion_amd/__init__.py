@@ -255,12 +255,14 @@ class BPGpu:
                                         _p(targ) if targ is not None else None, first.size,
                                         first.ctypes.data_as(C.POINTER(C.c_int32)), int(targ_offset)))
 
-    def train_frames(self, feat, targ, first_frame, fea_context, targ_offset):
+    def train_frames(self, feat, targ, first_frame, fea_context, targ_offset, wait=True):
+        """wait=False: mlggd_train_frames_async -- returns once the chunk is on the device and its steps are
+        enqueued (the arrays may be reused at once); sync() waits."""
         feat, targ, first = self._frames_args(feat, targ, first_frame, fea_context)
         trained = C.c_int(0)
-        _check(load().mlggd_train_frames(self._h, feat.shape[0], int(fea_context), _p(feat), _p(targ), first.size,
-                                         first.ctypes.data_as(C.POINTER(C.c_int32)), int(targ_offset),
-                                         C.byref(trained)))
+        fn = load().mlggd_train_frames if wait else load().mlggd_train_frames_async
+        _check(fn(self._h, feat.shape[0], int(fea_context), _p(feat), _p(targ), first.size,
+                  first.ctypes.data_as(C.POINTER(C.c_int32)), int(targ_offset), C.byref(trained)))
         return trained.value
 
     def cv_all_frames(self, feat, targ, first_frame, fea_context, targ_offset):

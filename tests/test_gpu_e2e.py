@@ -207,6 +207,38 @@ def test_launch_plan_knobs_do_not_change_a_bit(pkg, synth, monkeypatch, frames_m
             assert np.array_equal(x, y), (env, split)
 
 
+def test_chunks_enqueued_without_waiting_equal_chunks_trained_one_by_one(pkg, synth):
+    """mlggd_train_frames_async: four chunks of different sizes back to back (the upload of chunk i+1 goes to
+    the other device buffer set while chunk i's steps run, the host arrays are overwritten right after each
+    call) give bit-identical weights to the synchronous calls."""
+    dim, ctx, B, toff = 48, 5, 64, 2
+    ls = [dim * ctx, 128, 96, dim]
+    ws, bs = synth.make_weights(ls, seed=7)
+    rng = np.random.default_rng(8)
+    chunks = []
+    for nfr in (900, 500, 1300, 700):
+        feat = rng.standard_normal((nfr, dim), dtype=np.float32)
+        targ = (0.5 * feat + 0.5 * rng.standard_normal((nfr, dim), dtype=np.float32)).astype(np.float32)
+        first = rng.permutation(nfr - ctx + 1)[:(nfr // 70) * B // 2 + 5].astype(np.int32)
+        chunks.append((feat, targ, first))
+    a = pkg.BPGpu(1, 0, ls, B, *HP, ws, bs, 2.0, 0)
+    b = pkg.BPGpu(1, 0, ls, B, *HP, ws, bs, 2.0, 0)
+    for feat, targ, first in chunks:
+        a.train_frames(feat, targ, first, ctx, toff)
+    scratch_f = np.empty((1300, dim), np.float32)
+    for feat, targ, first in chunks:
+        f, t, i = feat.copy(), targ.copy(), first.copy()
+        b.train_frames(f, t, i, ctx, toff, wait=False)
+        f[:] = 7.0   # the caller's buffers are free as soon as the call returns
+        t[:] = -3.0
+        i[:] = 0
+    b.sync()
+    for x, y in zip(a.returnWeights()[0] + a.returnWeights()[1], b.returnWeights()[0] + b.returnWeights()[1]):
+        assert np.array_equal(x, y)
+    a.close()
+    b.close()
+
+
 def test_linearity_of_forward_at_full_size(pkg, synth):
     """Size-independent property at BASELINE size: with one linear layer the network output is
     linear in the input; f(a x1 + b x2) = a f(x1) + b f(x2) - (a+b-1) bias."""
