@@ -292,9 +292,8 @@ __device__ __forceinline__ void dx_body(const DxArgs &A, const int bid, float *s
     const int voD = (r8 * Bp + b0 + 4 * c4) * 4;
     float *wdst = wb + wr0 * DX_LDW + 4 * wc4;
     // rows of the dEdXt piece are stored with bits 0 and 1 of the row number swapped: the two half-waves of a
-    // fragment read (rows 4j and 4j+2, or 4j+1 and 4j+3) then sit 32 words apart, in different bank halves
-    // (stored in natural order they were 64 words apart = the same banks: a 2-way conflict on every read,
-    // 20 % of this kernel's LDS cycles in profiles/r01_sq_counters.txt)
+    // fragment read (rows 4j and 4j+2, or 4j+1 and 4j+3) then sit 32 words apart, in different bank halves,
+    // and the two values a lane needs per MFMA pair sit 64 words apart: one ds_read2st64_b32 (-0.8 us)
     float *ddst = db + ((r8 & ~3) | ((r8 & 1) << 1) | ((r8 >> 1) & 1)) * 32 + 4 * c4;
     const float *ard = wb + i * DX_LDW + 2 * h;
     const float *brd = db + h * 32 + i;
