@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep: random layer counts / sizes / bunch sizes / losses, 2-3 steps on the GPU against
+the CPU oracle (weights 2e-5 of max|W|, like tests/test_gpu_parity.py).  Expanded and frame-stream chunks,
+emulated data-parallel ranks where the shape allows.  SEED / N env vars."""
+import importlib, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+PKG = "speech-enhancement-based-on-a-maximum-likelihood-criterion_amd"
+pkg = importlib.import_module(PKG); synth = importlib.import_module(PKG + ".synth")
+from oracle import pyoracle
+
+rng = np.random.default_rng(int(os.environ.get("SEED", "1")))
+N = int(os.environ.get("N", "40"))
+HP = (0.1, 0.9, 1e-5)
+
+
+def relmax(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+worst = 0.0
+for case in range(N):
+    dim = int(rng.integers(3, 40)); ctx = int(rng.choice([1, 3, 5, 7]))
+    nh = int(rng.integers(0, 5))
+    ls = [dim * ctx] + [int(rng.integers(1, 300)) for _ in range(nh)] + [dim]
+    B = int(rng.choice([1, 7, 32, 50, 64, 100, 128, 192, 256, 300]))
+    ml, beta = [(0, 2.0), (0, 1.0), (1, 2.0), (1, 1.2), (1, 0.9)][int(rng.integers(0, 5))]
+    if ml == 1 and B < 7:
+        ml, beta = 0, 2.0  # the ML gradient is ~1/|e| with a one-frame minibatch: ill-conditioned, not a parity case
+    steps = int(rng.integers(1, 4))
+    world = 1
+    if B % 32 == 0 and rng.random() < 0.4:
+        cands = [w for w in (2, 4, 8) if w * B in (64, 128, 256, 512, 1024)]
+        if cands:
+            world = int(rng.choice(cands))
+    sharded = bool(world > 1 and rng.random() < 0.5)
+    frames_mode = bool(world == 1 and rng.random() < 0.4)
+    ws, bs = synth.make_weights(ls, seed=100 + case)
+    bs = [rng.uniform(-0.1, 0.1, b.shape).astype(np.float32) for b in bs]
+    nfr = steps * B + ctx + 40
+    feat = rng.standard_normal((nfr, dim), dtype=np.float32)
+    targ_fr = (0.5 * feat + 0.5 * rng.standard_normal((nfr, dim), dtype=np.float32)).astype(np.float32)
+    first = rng.permutation(nfr - ctx + 1)[:steps * B + int(rng.integers(0, 5))].astype(np.int32)
+    toff = int(rng.integers(0, ctx))
+    steps = len(first) // B  # a small B turns the ragged tail into extra full bunches
+    idx = first[:, None] + np.arange(ctx)[None, :]
+    inp = np.ascontiguousarray(feat[idx].reshape(len(first), ctx * dim))
+    tg = np.ascontiguousarray(targ_fr[first + toff])
+    eng = pkg.BPGpu(1, 0, ls, B, *HP, ws, bs, beta, ml)
+    if world > 1:
+        eng.fake_world(world, sharded)
+    ora = pyoracle.OracleNet(ls, world * B, *HP, beta, ml, ws, bs)
+    if frames_mode:
+        got = eng.train_frames(feat, targ_fr, first, ctx, toff)
+    else:
+        got = eng.train(inp, tg)
+    gi = np.concatenate([np.tile(inp[s * B:(s + 1) * B], (world, 1)) for s in range(steps)]) if world > 1 else inp
+    gt = np.concatenate([np.tile(tg[s * B:(s + 1) * B], (world, 1)) for s in range(steps)]) if world > 1 else tg
+    exp = ora.train(gi, gt)
+    assert got == steps and exp == steps, (got, exp, steps)
+    we, be = eng.returnWeights(); wo, bo = ora.get_weights()
+    err = max(max(relmax(a, b) for a, b in zip(we, wo)), max(relmax(a, b) for a, b in zip(be, bo)))
+    worst = max(worst, err)
+    # one-frame minibatches take steps of the order of the weights themselves: rounding differences are amplified
+    tol = 2e-5 if B >= 7 else 2e-4
+    tag = "ok " if err < tol else "BAD"
+    print("%s case %2d: layers %-28s B %3d  loss (%d,%.1f) steps %d world %d%s%s  err %.1e" %
+          (tag, case, ls, B, ml, beta, steps, world, " sharded" if sharded else "", " frames" if frames_mode else "", err),
+          flush=True)
+    assert err < tol
+    eng.close(); ora.close()
+print("all %d cases within tolerance; worst %.1e" % (N, worst))
