@@ -118,6 +118,8 @@ int mlggd_forward_frames(mlggd_handle h, int n_frames, int fea_context, const fl
                          const int32_t *first_frame, float *out);
 /* pinned host memory for chunk buffers (optional; faster H2D than pageable memory) */
 int mlggd_alloc_pinned(size_t bytes, void **out);
+/* the same from a thread that has not selected a device (host IO threads): pins through `device`'s context */
+int mlggd_alloc_pinned_on(int device, size_t bytes, void **out);
 int mlggd_free_pinned(void *p);
 
 /* ---- state: BP_GPU::returnWeights (BP_GPU.cu:514-525) and dev.scalefactor (:287) ---- */
@@ -126,6 +128,11 @@ int mlggd_set_weights(mlggd_handle h, const float *const *weights, const float *
 int mlggd_get_scalefactor(mlggd_handle h, float *alpha /* [D] */);
 int mlggd_set_scalefactor(mlggd_handle h, const float *alpha /* [D] */);
 int mlggd_set_lrate(mlggd_handle h, float lrate);
+/* CV metrics: on = the three sums are formed on the device (per-tile partials in double, combined
+ * on the host; no n x D copy, no host loop); off (default, or env MLGGD_CV_DEVICE=0) = outputs copied back and
+ * accumulated on the host in fp32 in the reference's frame-major order (BP_GPU.cu:207-213), the values the
+ * reference's log lines carry.  The two differ by the rounding of that fp32 accumulation (~1e-5 relative). */
+int mlggd_set_cv_device_reduce(mlggd_handle h, int on);
 float mlggd_gamma(float x); /* BP_GPU::Gamma, BP_GPU.cu:593-640 */
 
 /* Copies an internal tensor of the LAST step to the host in the reference's row-major
@@ -136,10 +143,15 @@ int mlggd_debug_tensor(mlggd_handle h, const char *name, int layer, float *dst, 
 
 /* ---- data parallel over the GPUs of one node (new work): one process per
  * GPU; rank r trains rows [r*bunchsize,(r+1)*bunchsize) of every global minibatch of
- * world*bunchsize frames.  Exchanges per step (RCCL, fp32 sum): the per-dimension
- * sum |e|^beta (ML only) and the weight/bias gradients; every 1/n_frames factor uses the
- * GLOBAL minibatch size, so the run equals a single-device run with bunchsize =
- * world*bunchsize.  rank 0 fills a unique id, the caller broadcasts it out of band. */
+ * world*bunchsize frames.  Exchanges per step (RCCL): the per-dimension sum |e|^beta (ML only,
+ * all-reduce of 257 floats) and ONE of three forms of the gradient exchange (mlggd_dp_mode below):
+ * an all-reduce of the weight/bias gradients; an all-gather of the gradient's FACTORS (every rank's
+ * Y_{l-1} and dEdX_l rows) after which each rank forms the global-minibatch gradient itself; or the
+ * factor all-gather with each rank updating only its block of weight rows, followed by an all-gather
+ * of W.  Every 1/n_frames factor uses the GLOBAL minibatch size, so the run equals a single-device
+ * run with bunchsize = world*bunchsize.  rank 0 fills a unique id, the caller broadcasts it out of
+ * band.  Status: tested on one GPU only (1-rank communicator; emulated worlds of 2-8 ranks with
+ * different rows per rank); never run between two GPUs -- the mode thresholds are a cost model. */
 int mlggd_comm_unique_id(void *id /* MLGGD_UNIQUE_ID_BYTES */);
 int mlggd_comm_init(mlggd_handle h, const void *id, int world_size, int rank);
 
@@ -165,11 +177,15 @@ int mlggd_kernel_work(mlggd_handle h, const char *kernel_class, int layer, doubl
 int mlggd_dw_launches_per_step(mlggd_handle h, int *launches);
 /* 0 = single device, 1 = data parallel by all-reduce of the weight gradients, 2 = by all-gather of their
  * factors with the update replicated on every rank, 3 = the same with the update sharded over the ranks and
- * W all-gathered (defaults: 2 up to 7 ranks, 3 from 8 ranks, 1 where the shape rules out the gather;
- * MLGGD_DP_MODE=allreduce|gather|shard at comm init) */
+ * W all-gathered (defaults: 2 up to 5 ranks, 3 from 6 ranks, 1 where the shape rules out the gather --
+ * bunchsize % 32 != 0 or world*bunchsize not in {64,128,256,512,1024}; MLGGD_DP_MODE=allreduce|gather|shard
+ * at comm init overrides) */
 int mlggd_dp_mode(mlggd_handle h, int *mode);
-/* Test hook: emulate `world_size` identical ranks on one GPU (device copies instead of collectives). */
-int mlggd_debug_fake_world(mlggd_handle h, int world_size, int sharded);
+/* Test hook: emulate `world_size` ranks on one GPU (device copies / adds instead of collectives).  Every
+ * training step then consumes world_size*bunchsize rows of the resident chunk, emulated rank r owning rows
+ * [r*bunchsize,(r+1)*bunchsize) of them.  mode: 0 = factor all-gather + replicated update, 1 = factor
+ * all-gather + sharded update, 2 = gradient all-reduce. */
+int mlggd_debug_fake_world(mlggd_handle h, int world_size, int mode);
 
 /* Diagnostic (not part of the reference surface): in-kernel phase stamps of the NEXT launch of
  * (class "fwd"|"dx"|"dw", layer): 8 int64 slots per workgroup in 100 MHz ticks

@@ -16,8 +16,20 @@
  *  (iv)  the gradient is divided by n_frames twice (loss gradient and update).
  *  (vi)  CrossValid2 uses the alpha of the last training minibatch.
  *  (vii) delta buffers start at zero.
- * Built with -ffp-contract=off so no a*b+c is fused; OpenMP only splits independent
- * output elements across threads, so results do not depend on the thread count.
+ *  (viii) FMA contraction.  The reference is built with plain `nvcc -g` (Makefile:30-33), i.e. the default
+ *        --fmad=true: inside its elementwise kernels an a*b+c such as kernUpdatedelta's
+ *        `momentum*delta - lr*(g/n + wc*w)` (DevFunc.cu:502) or kernAccSum's `a*x + y` (DevFunc.cu:440) is
+ *        contracted into one fused multiply-add wherever the compiler sees fit, and cuBLAS sgemm uses FMAs
+ *        throughout.  Which products are fused is a compiler decision no source reading can settle.  This
+ *        oracle (and the HIP build, csrc/Makefile) takes the UNFUSED reading: built with -ffp-contract=off.
+ *        The same source built with -ffp-contract=fast -mfma (libmlggd_oracle_fma.so) gives the fused
+ *        reading; tests/test_oracle.py::test_fma_contraction_variant_is_inside_the_gpu_tolerances measures
+ *        the distance between the two: weights and biases 0.7-4.4e-7 of their maximum after 3 steps on the
+ *        tiny net and after 2 steps at 2827-2048^3-257 (MMSE, ML beta 1.2, ML beta 0.9), CV metrics within 1e-5
+ *        relative -- the test requires 2e-6 / 1e-5, ten times inside the GPU tolerances (weights 2e-5, CV 1e-4),
+ *        so either reading of the reference passes the same parity tests.
+ * OpenMP only splits independent output elements across threads, so results do not depend on the
+ * thread count.
  */
 #include "mlggd_oracle.h"
 

@@ -11,24 +11,24 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "libmlggd_oracle.so")
-_lib = None
+_LIB_FMA = os.path.join(_HERE, "libmlggd_oracle_fma.so")  # same source, FMA contraction on (ambiguity viii)
+_libs = {}
 
 _fp = C.POINTER(C.c_float)
 _fpp = C.POINTER(_fp)
 
 
 def build(force=False):
-    if force or not os.path.exists(_LIB) or (
-        os.path.getmtime(_LIB) < os.path.getmtime(os.path.join(_HERE, "mlggd_oracle.c"))
-    ):
-        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    src = os.path.getmtime(os.path.join(_HERE, "mlggd_oracle.c"))
+    if force or any(not os.path.exists(p) or os.path.getmtime(p) < src for p in (_LIB, _LIB_FMA)):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
 
 
-def lib():
-    global _lib
-    if _lib is None:
+def lib(variant="strict"):
+    """variant "strict": no a*b+c is fused (the oracle every parity test uses); "fma": contraction on."""
+    if variant not in _libs:
         build()
-        L = C.CDLL(_LIB)
+        L = C.CDLL({"strict": _LIB, "fma": _LIB_FMA}[variant])
         L.ora_create.restype = C.c_void_p
         L.ora_create.argtypes = [C.c_int, C.POINTER(C.c_int), C.c_int, C.c_float, C.c_float,
                                  C.c_float, C.c_float, C.c_int, _fpp, _fpp]
@@ -57,8 +57,8 @@ def lib():
             # a container often sees all host CPUs but may only use a share of them: more threads than
             # that share makes every OpenMP region slower, not faster
             L.ora_set_num_threads(usable_cpus())
-        _lib = L
-    return _lib
+        _libs[variant] = L
+    return _libs[variant]
 
 
 def usable_cpus():
@@ -105,7 +105,8 @@ class OracleNet:
     """Mirror of the reference's class BP_GPU (BP_GPU.h:45-70) on the CPU oracle."""
 
     def __init__(self, layersizes, bunchsize, lrate, momentum, weightcost, shapefactor, MLflag,
-                 weights, bias):
+                 weights, bias, variant="strict"):
+        self._lib = lib(variant)
         self.layersizes = [int(x) for x in layersizes]
         self.L = len(self.layersizes)
         self.bunchsize = int(bunchsize)
@@ -116,13 +117,13 @@ class OracleNet:
         for l in range(1, self.L):
             assert self._w[l - 1].shape == (self.layersizes[l - 1], self.layersizes[l])
         ls = (C.c_int * self.L)(*self.layersizes)
-        self._h = lib().ora_create(self.L, ls, self.bunchsize, lrate, momentum, weightcost,
+        self._h = self._lib.ora_create(self.L, ls, self.bunchsize, lrate, momentum, weightcost,
                                    shapefactor, int(MLflag), _ptr_array(self._w), _ptr_array(self._b))
         assert self._h
 
     def close(self):
         if self._h:
-            lib().ora_destroy(self._h)
+            self._lib.ora_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -134,71 +135,71 @@ class OracleNet:
     def train(self, inp, targ):
         inp, pi = _f32(inp)
         targ, pt = _f32(targ)
-        return lib().ora_train(self._h, inp.shape[0], pi, pt)
+        return self._lib.ora_train(self._h, inp.shape[0], pi, pt)
 
     def train_bunch(self, inp, targ):
         inp, pi = _f32(inp)
         targ, pt = _f32(targ)
-        lib().ora_train_bunch(self._h, inp.shape[0], pi, pt)
+        self._lib.ora_train_bunch(self._h, inp.shape[0], pi, pt)
 
     # phases (data-parallel contract)
     def forward(self, inp):
         inp, pi = _f32(inp)
-        lib().ora_forward(self._h, inp.shape[0], pi)
+        self._lib.ora_forward(self._h, inp.shape[0], pi)
 
     def loss_colsum(self, targ):
         targ, pt = _f32(targ)
         out = np.zeros(self.D, np.float32)
-        lib().ora_loss_colsum(self._h, targ.shape[0], pt, out.ctypes.data_as(_fp))
+        self._lib.ora_loss_colsum(self._h, targ.shape[0], pt, out.ctypes.data_as(_fp))
         return out
 
     def loss_grad(self, targ, n_global, colsum):
         targ, pt = _f32(targ)
         cs, pc = _f32(colsum)
-        lib().ora_loss_grad(self._h, targ.shape[0], int(n_global), pt, pc)
+        self._lib.ora_loss_grad(self._h, targ.shape[0], int(n_global), pt, pc)
 
     def backward(self, inp):
         inp, pi = _f32(inp)
-        lib().ora_backward(self._h, inp.shape[0], pi)
+        self._lib.ora_backward(self._h, inp.shape[0], pi)
 
     def apply_update(self, n_global):
-        lib().ora_apply_update(self._h, int(n_global))
+        self._lib.ora_apply_update(self._h, int(n_global))
 
     def cv_forward(self, inp):
         inp, pi = _f32(inp)
         out = np.zeros((inp.shape[0], self.D), np.float32)
-        lib().ora_cv_bunch(self._h, inp.shape[0], pi, out.ctypes.data_as(_fp))
+        self._lib.ora_cv_bunch(self._h, inp.shape[0], pi, out.ctypes.data_as(_fp))
         return out
 
     def cv_sqerr(self, inp, targ):
         inp, pi = _f32(inp)
         targ, pt = _f32(targ)
-        return float(lib().ora_cv_sqerr(self._h, inp.shape[0], pi, pt))
+        return float(self._lib.ora_cv_sqerr(self._h, inp.shape[0], pi, pt))
 
     def cv_abserr(self, inp, targ):
         inp, pi = _f32(inp)
         targ, pt = _f32(targ)
-        return float(lib().ora_cv_abserr(self._h, inp.shape[0], pi, pt))
+        return float(self._lib.ora_cv_abserr(self._h, inp.shape[0], pi, pt))
 
     def cv_loglik(self, inp, targ):
         inp, pi = _f32(inp)
         targ, pt = _f32(targ)
-        return float(lib().ora_cv_loglik(self._h, inp.shape[0], pi, pt))
+        return float(self._lib.ora_cv_loglik(self._h, inp.shape[0], pi, pt))
 
     def get_weights(self):
         ws = [np.zeros((self.layersizes[l - 1], self.layersizes[l]), np.float32) for l in range(1, self.L)]
         bs = [np.zeros(self.layersizes[l], np.float32) for l in range(1, self.L)]
-        lib().ora_get_weights(self._h, _ptr_array(ws), _ptr_array(bs))
+        self._lib.ora_get_weights(self._h, _ptr_array(ws), _ptr_array(bs))
         return ws, bs
 
     def set_scalefactor(self, alpha):
         a, pa = _f32(alpha)
         assert a.shape == (self.D,)
-        lib().ora_set_scalefactor(self._h, pa)
+        self._lib.ora_set_scalefactor(self._h, pa)
 
     def tensor(self, name, layer=0, rows=None):
         cnt = C.c_long(0)
-        p = lib().ora_tensor(self._h, name.encode(), int(layer), C.byref(cnt))
+        p = self._lib.ora_tensor(self._h, name.encode(), int(layer), C.byref(cnt))
         if not p:
             raise KeyError(name)
         a = np.ctypeslib.as_array(p, shape=(cnt.value,)).copy()

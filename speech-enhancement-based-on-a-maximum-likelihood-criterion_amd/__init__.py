@@ -47,7 +47,7 @@ EXPORTS = [
     "mlggd_kernel_work", "mlggd_dw_launches_per_step", "mlggd_dp_mode", "mlggd_debug_fake_world",
     "mlggd_debug_stamp_select", "mlggd_debug_stamp_read",
     "mlggd_load_frames", "mlggd_train_frames", "mlggd_train_frames_async", "mlggd_cv_all_frames", "mlggd_forward_frames",
-    "mlggd_alloc_pinned", "mlggd_free_pinned",
+    "mlggd_alloc_pinned", "mlggd_alloc_pinned_on", "mlggd_free_pinned", "mlggd_set_cv_device_reduce",
 ]
 
 _lib = None
@@ -92,6 +92,8 @@ def load():
     L.mlggd_get_scalefactor.argtypes = [C.c_void_p, _fp]
     L.mlggd_set_scalefactor.argtypes = [C.c_void_p, _fp]
     L.mlggd_set_lrate.argtypes = [C.c_void_p, C.c_float]
+    L.mlggd_set_cv_device_reduce.argtypes = [C.c_void_p, C.c_int]
+    L.mlggd_alloc_pinned_on.argtypes = [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]
     L.mlggd_debug_tensor.argtypes = [C.c_void_p, C.c_char_p, C.c_int, _fp, C.c_size_t]
     L.mlggd_comm_unique_id.argtypes = [C.c_void_p]
     L.mlggd_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
@@ -396,8 +398,14 @@ class BPGpu:
         _check(load().mlggd_dp_mode(self._h, C.byref(n)))
         return n.value
 
-    def fake_world(self, world_size, sharded=False):
-        _check(load().mlggd_debug_fake_world(self._h, int(world_size), 1 if sharded else 0))
+    def set_cv_device_reduce(self, on=True):
+        """CV sums formed on the device (no n x D copy back) instead of the reference-order host loop."""
+        _check(load().mlggd_set_cv_device_reduce(self._h, 1 if on else 0))
+
+    def fake_world(self, world_size, sharded=False, allreduce=False):
+        """Emulate world_size ranks on this GPU: every step consumes world_size*bunchsize rows, rank r owns
+        rows [r*bunchsize,(r+1)*bunchsize) of them (test hook, mlggd_debug_fake_world)."""
+        _check(load().mlggd_debug_fake_world(self._h, int(world_size), 2 if allreduce else 1 if sharded else 0))
 
     def stamp_select(self, kernel_class, layer):
         _check(load().mlggd_debug_stamp_select(self._h, kernel_class.encode(), int(layer)))

@@ -119,11 +119,18 @@ struct mlggd_engine {
     float *G[MLGGD_MAXLAYER] = {0}, *gb[MLGGD_MAXLAYER] = {0};
     float *gb_all = nullptr;
     size_t gb_all_count = 0;
+    // one-GPU emulation of a world (mlggd_debug_fake_world): sums over the emulated ranks 0..world-2
+    float *Gpre[MLGGD_MAXLAYER] = {0}, *gbpre = nullptr, *colsum_tot = nullptr;
     float *Yt[MLGGD_MAXLAYER] = {0}, *Y[MLGGD_MAXLAYER] = {0};
     float *dEdXt[MLGGD_MAXLAYER] = {0}, *dEdX[MLGGD_MAXLAYER] = {0};
     float *slab = nullptr, *outT = nullptr, *eT = nullptr, *pT = nullptr, *colsum = nullptr, *scalefactor = nullptr;
     int S_out = 1;
     float *chunk_in = nullptr, *chunk_targ = nullptr, *chunk_out = nullptr;
+    // CV metrics: 0 = outputs copied back, host fp32 accumulation in the reference's order (default: it is what
+    // the log lines are compared on); 1 = sums formed on the device (k_cv_reduce), nothing of size n x D leaves it
+    int cv_device = 0;
+    double *cv_partial = nullptr;
+    size_t cv_partial_cap = 0;
     size_t chunk_cap = 0, out_cap = 0;
     int chunk_frames = 0;
     // indexed chunk: raw frame streams + first frame of every sample row
@@ -156,7 +163,7 @@ struct mlggd_engine {
     int shard_rows[MLGGD_MAXLAYER] = {0};  // 64-row tile rows of layer l owned by each rank
     hipEvent_t ev_W[MLGGD_MAXLAYER] = {0}, ev_dw_done = nullptr;
     bool ev_W_pending[MLGGD_MAXLAYER] = {false};
-    bool fake_world = false;  // test hook: `world` identical ranks emulated with device copies, no communicator
+    bool fake_world = false;  // test hook: `world` ranks emulated one after the other on this GPU, no communicator
     float *Yall[MLGGD_MAXLAYER] = {0}, *dEdXall[MLGGD_MAXLAYER] = {0};
     hipEvent_t ev_ready = nullptr, ev_gathered = nullptr;
     // fine-grained factor exchange (few ranks: cheap collectives, few links): every factor is sent as soon as it
@@ -182,6 +189,7 @@ struct mlggd_engine {
     size_t stamp_cap = 0;
 
     std::vector<void *> allocs;
+    std::vector<const void *> lds_attr_done;  // kernels whose dynamic-LDS limit has been raised on this device
 };
 
 // buffer for the selected launch, nullptr otherwise; one-shot
@@ -242,14 +250,14 @@ static int launch_check(const char *what) {
 }
 
 template <typename F>
-static int ensure_lds(F fn, size_t bytes) {
-    // kernels with > 64 KB of dynamic LDS need the attribute; cache by function address
-    static std::vector<const void *> done;
+static int ensure_lds(mlggd_engine *e, F fn, size_t bytes) {
+    // kernels with > 64 KB of dynamic LDS need the attribute.  It is a per-device property of the loaded code
+    // object, so the "already set" list lives in the engine (one engine = one device), not in the process.
     const void *key = (const void *)fn;
-    for (const void *d : done)
+    for (const void *d : e->lds_attr_done)
         if (d == key) return MLGGD_OK;
     HIPCHK(hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    done.push_back(key);
+    e->lds_attr_done.push_back(key);
     return MLGGD_OK;
 }
 
@@ -427,7 +435,7 @@ static int run_forward(mlggd_engine *e, const Bunch &bn, int frames, bool traini
 #define LAUNCH_FWD(NW)                                                                                      \
     {                                                                                                       \
         const size_t lds = fwd_lds_floats<NW>() * sizeof(float);                                            \
-        CHK(ensure_lds(k_fwd<FWD_SIGMOID, NW>, lds));                                                       \
+        CHK(ensure_lds(e, k_fwd<FWD_SIGMOID, NW>, lds));                                                       \
         hipLaunchKernelGGL((k_fwd<FWD_SIGMOID, NW>), dim3(n_tiles * b_tiles), dim3(64 * NW), lds, e->stream, fa, st); \
     }
                 if (e->fwd_nw == 16) LAUNCH_FWD(16)
@@ -467,12 +475,8 @@ static int launch_dw(mlggd_engine *e, int l, const float *in_rows, bool fused, f
     const float *A = (l == 1) ? in_rows : e->Y[l - 1];
     const int ldA = (l == 1) ? e->K0 : Kp;
     const size_t lds = (size_t)2 * (64 * T) * (64 * T) * sizeof(float);
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[fused ? 1 : 0]) {
-        const void *fn = fused ? (const void *)k_dw<T, true> : (const void *)k_dw<T, false>;
-        HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set[fused ? 1 : 0] = true;
-    }
+    if (fused) CHK(ensure_lds(e, k_dw<T, true>, lds));
+    else CHK(ensure_lds(e, k_dw<T, false>, lds));
     if (fused)
         hipLaunchKernelGGL((k_dw<T, true>), dim3(k_wg * n_wg), dim3(256), lds, st, A, ldA, e->dEdX[l], e->W[l],
                            e->dW[l], (float *)nullptr, e->bias[l], e->dbias[l], (float *)nullptr, e->ls[l - 1], e->ls[l], Np,
@@ -511,10 +515,10 @@ static int launch_dwp_t(mlggd_engine *e, const DwpJobs &J, bool fused, hipStream
     const int grid = dwp_grid(e, J.total);
     long long *stamps = stamps_for(e, KC_DW, stamp_layer, grid);
     if (fused) {
-        CHK(ensure_lds(k_dwp<H, true>, lds));
+        CHK(ensure_lds(e, k_dwp<H, true>, lds));
         hipLaunchKernelGGL((k_dwp<H, true>), dim3(grid), dim3(256), lds, st, J, stamps);
     } else {
-        CHK(ensure_lds(k_dwp<H, false>, lds));
+        CHK(ensure_lds(e, k_dwp<H, false>, lds));
         hipLaunchKernelGGL((k_dwp<H, false>), dim3(grid), dim3(256), lds, st, J, stamps);
     }
     return launch_check("k_dwp");
@@ -565,10 +569,9 @@ static int gather_alloc(mlggd_engine *e) {
 }
 // one rank's block -> every rank's slot r of dst (on the communication stream)
 static int gather_one(mlggd_engine *e, const float *src, float *dst, size_t count) {
-    if (e->fake_world) {
-        for (int r = 0; r < e->world; r++)
-            HIPCHK(hipMemcpyAsync(dst + (size_t)r * count, src, count * sizeof(float), hipMemcpyDeviceToDevice,
-                                  e->comm_stream));
+    if (e->fake_world) {  // the other ranks' slots were filled by fake_world_prepass
+        HIPCHK(hipMemcpyAsync(dst + (size_t)e->rank * count, src, count * sizeof(float), hipMemcpyDeviceToDevice,
+                              e->comm_stream));
         return MLGGD_OK;
     }
     NCCLCHK(g_rccl.AllGather(src, dst, count, 7 /* ncclFloat32 */, e->comm, e->comm_stream));
@@ -679,19 +682,162 @@ static BiasJobs make_bias_jobs(mlggd_engine *e) {
     return jobs;
 }
 
+// ---- pieces of one step ----------------------------------------------------------------------------
+// Where the per-dimension sum of |e|^beta of the ML loss (BP_GPU.cu:416) comes from:
+enum ColsumSource {
+    CS_LOCAL = 0,   // single device: every loss workgroup sums its own 32 columns of the minibatch
+    CS_ALLREDUCE,   // data parallel: local sums (k_colsum), all-reduced over the communicator
+    CS_GIVEN,       // e->colsum_tot already holds the global sum (one-GPU emulation of a world)
+    CS_ACCUMULATE   // emulation, first pass: error + local sums only, added into e->colsum_tot; no gradient
+};
+// largest dynamic LDS the loss kernels are ever launched with (bunchsize 1152, the cap mlggd_create enforces)
+constexpr size_t LOSS_LDS_MAX = (size_t)(32 * (1152 + 1) + 32) * sizeof(float);
+
+// Output-layer loss of one minibatch: BP_GPU.cu:408-423.  sa / n_stage: input-staging blocks of the NEXT
+// minibatch that ride along with the first loss launch (n_stage 0: none).
+static int run_loss(mlggd_engine *e, const Bunch &bn, float nf, float inv_n, ColsumSource cs, bool first_acc,
+                    const StageArgs &sa, int n_stage) {
+    const int L = e->L, B = e->B, Bp = e->Bp, b_tiles = Bp / 32, ML = e->cfg.MLflag;
+    ProfScope ps(e, KC_LOSS, 0);
+    const size_t lds = (size_t)(32 * (Bp + 1) + 32) * sizeof(float);
+    const int n_loss = (e->Dp / 32) * b_tiles;
+    if (ML != 1 && e->loss_fuse) {
+        if (cs == CS_ACCUMULATE) return MLGGD_OK;  // no minibatch statistic without the ML loss
+        LossNormArgs la;
+        la.slab = e->slab; la.S = e->S_out; la.bias = e->bias[L - 1]; la.targ = bn.targ;
+        la.B = B; la.D = e->D; la.Dp = e->Dp; la.Bp = Bp; la.beta = e->cfg.shapefactor; la.inv_n = inv_n;
+        la.outT = e->outT; la.eT = e->eT; la.dEdXt = e->dEdXt[L - 1]; la.dEdX = e->dEdX[L - 1];
+        la.b_tiles = b_tiles; la.first = bn.first; la.toff = e->toff;
+        hipLaunchKernelGGL(k_loss_norm, dim3(n_loss + n_stage), dim3(256), 0, e->stream, la, n_loss, sa);
+        return launch_check("k_loss_norm");
+    }
+    LossErrArgs la;
+    la.slab = e->slab; la.S = e->S_out; la.bias = e->bias[L - 1]; la.targ = bn.targ;
+    la.B = B; la.D = e->D; la.Dp = e->Dp; la.Bp = Bp; la.beta = e->cfg.shapefactor; la.want_pow = ML == 1 ? 1 : 0;
+    la.outT = e->outT; la.eT = e->eT; la.pT = e->pT;
+    la.b_tiles = b_tiles; la.first = bn.first; la.toff = e->toff;
+    hipLaunchKernelGGL(k_loss_err, dim3(n_loss + n_stage), dim3(256), 0, e->stream, la, n_loss, sa);
+    CHK(launch_check("k_loss_err"));
+    const float *colsum_in = nullptr;
+    if (ML == 1 && cs == CS_GIVEN) {
+        colsum_in = e->colsum_tot;
+    } else if (ML == 1 && cs != CS_LOCAL) {
+        CHK(ensure_lds(e, k_colsum, LOSS_LDS_MAX));
+        hipLaunchKernelGGL(k_colsum, dim3(e->Dp / 32), dim3(256), lds, e->stream, e->pT, B, Bp, e->colsum);
+        CHK(launch_check("k_colsum"));
+        if (cs == CS_ACCUMULATE) {
+            hipLaunchKernelGGL(k_accum, dim3(1), dim3(256), 0, e->stream, e->colsum_tot,
+                               first_acc ? (const float *)nullptr : (const float *)e->colsum_tot, (const float *)e->colsum,
+                               (size_t)e->Dp);
+            return launch_check("k_accum");
+        }
+        NCCLCHK(g_rccl.AllReduce(e->colsum, e->colsum, (size_t)e->Dp, 7, 0, e->comm, e->stream));
+        colsum_in = e->colsum;
+    }
+    if (cs == CS_ACCUMULATE) return MLGGD_OK;
+    CHK(ensure_lds(e, k_loss_grad, LOSS_LDS_MAX));
+    hipLaunchKernelGGL(k_loss_grad, dim3(n_loss), dim3(256), lds, e->stream, e->eT, e->pT, colsum_in, B, e->D, e->Dp, Bp,
+                       e->cfg.shapefactor, ML, nf, inv_n, e->scalefactor, e->dEdXt[L - 1], e->dEdX[L - 1], b_tiles);
+    return launch_check("k_loss_grad");
+}
+
+// dEdX_{l-1} from dEdX_l and the OLD W_l (+ sigmoid derivative of layer l-1): BP_GPU.cu:402,430
+static int run_dx(mlggd_engine *e, int l) {
+    const int Kp = e->lsp[l - 1], b_tiles = e->Bp / 32;
+    ProfScope ps(e, KC_DX, l);
+    long long *st = stamps_for(e, KC_DX, l, (Kp / 32) * b_tiles);
+    DxArgs xa = dx_args(e, l);
+    if (e->dx_nw == 8) {
+        const size_t lds = dx_lds_floats<8>() * sizeof(float);
+        CHK(ensure_lds(e, k_dx<8>, lds));
+        hipLaunchKernelGGL(k_dx<8>, dim3((Kp / 32) * b_tiles), dim3(512), lds, e->stream, xa, st);
+    } else {
+        const size_t lds = dx_lds_floats<4>() * sizeof(float);
+        CHK(ensure_lds(e, k_dx<4>, lds));
+        hipLaunchKernelGGL(k_dx<4>, dim3((Kp / 32) * b_tiles), dim3(256), lds, e->stream, xa, st);
+    }
+    return launch_check("k_dx");
+}
+
+// the weight-gradient kernel of ONE layer (fused: with the update as its epilogue; else G_l, gb_l are written)
+static int launch_dw_layer(mlggd_engine *e, int l, const float *in_rows, bool fused, float nf, hipStream_t st) {
+    const int Kp = e->lsp[l - 1], Np = e->lsp[l];
+    const long tiles128 = (long)((Kp + 127) / 128) * ((Np + 127) / 128);
+    const bool big = e->dw_tile == 0 ? tiles128 >= 192 : e->dw_tile == 2;
+    ProfScope ps(e, KC_DW, l, st);
+    if (dwp_usable(e)) return launch_dwp(e, dwp_jobs(e, l, l, in_rows, nf), fused, st, l);
+    if (big) return launch_dw<2>(e, l, in_rows, fused, nf, st);
+    return launch_dw<1>(e, l, in_rows, fused, nf, st);
+}
+
+static int launch_accum(float *dst, const float *a, const float *b, size_t n, hipStream_t st) {
+    const size_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(k_accum, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, st, dst, a, b, n);
+    return launch_check("k_accum");
+}
+
+// One-GPU emulation of a world of ranks (mlggd_debug_fake_world).  The global minibatch is rows
+// [sample0, sample0 + world*B) of the resident chunk and emulated rank r owns rows [sample0 + r*B, +B) of it:
+// the partition of SURVEY 8e, with DIFFERENT rows on every rank.  Ranks 0 .. world-2 run here, one after the
+// other, and leave behind what the collectives would have delivered: the ML statistic of ALL ranks in
+// colsum_tot, their factors in slot r of Yall / dEdXall (gather modes), or their gradients summed into
+// Gpre / gbpre (all-reduce mode).  The last rank then takes the real data-parallel path of run_step with
+// device copies / adds in place of the RCCL calls.
+static int fake_world_prepass(mlggd_engine *e, int sample0, float nf, float inv_n) {
+    const int L = e->L, B = e->B, Bp = e->Bp, W = e->world;
+    StageArgs none;
+    memset(&none, 0, sizeof(none));
+    if (e->cfg.MLflag == 1)
+        for (int r = 0; r < W; r++) {
+            const Bunch bn = bunch_at(e, sample0 + r * B);
+            CHK(run_forward(e, bn, B, true));
+            CHK(run_loss(e, bn, nf, inv_n, CS_ACCUMULATE, r == 0, none, 0));
+        }
+    for (int r = 0; r + 1 < W; r++) {
+        const Bunch bn = bunch_at(e, sample0 + r * B);
+        CHK(run_forward(e, bn, B, true));
+        const float *in_rows = bunch_rows(e, bn);
+        CHK(run_loss(e, bn, nf, inv_n, CS_GIVEN, false, none, 0));
+        for (int l = L - 1; l >= 2; l--) CHK(run_dx(e, l));
+        if (e->dp_mode >= 1) {
+            auto put = [&](const float *src, float *dst, size_t count) -> int {
+                HIPCHK(hipMemcpyAsync(dst + (size_t)r * count, src, count * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
+                return MLGGD_OK;
+            };
+            CHK(put(in_rows, e->Yall[0], (size_t)B * e->K0));
+            for (int l = 1; l < L; l++) {
+                if (l != L - 1) CHK(put(e->Y[l], e->Yall[l], (size_t)Bp * e->lsp[l]));
+                CHK(put(e->dEdX[l], e->dEdXall[l], (size_t)Bp * e->lsp[l]));
+            }
+        } else {
+            for (int l = L - 1; l >= 1; l--) {
+                CHK(launch_dw_layer(e, l, in_rows, false, nf, e->stream));
+                CHK(launch_accum(e->Gpre[l], r == 0 ? nullptr : e->Gpre[l], e->G[l], (size_t)e->lsp[l - 1] * e->lsp[l], e->stream));
+            }
+            CHK(launch_accum(e->gbpre, r == 0 ? nullptr : e->gbpre, e->gb_all, e->gb_all_count, e->stream));
+        }
+    }
+    return MLGGD_OK;
+}
+
 // One SGD step on `frames` (= bunchsize) resident frames: BP_GPU::train_bunch_single,
 // BP_GPU.cu:308-440.
 // next != nullptr: also stage that bunch's input for the following step (its blocks ride along
 // with the loss kernel; see k_loss_norm).  prestaged: this bunch was staged that way.
-static int run_step(mlggd_engine *e, const Bunch &bn, bool prestaged = false, const Bunch *next = nullptr) {
-    const float *targ_rows = bn.targ;
-    const int L = e->L, B = e->B, Bp = e->Bp, b_tiles = Bp / 32;
+// sample0: index of the minibatch's first row in the resident chunk (only the emulated world needs it).
+static int run_step(mlggd_engine *e, int sample0, bool prestaged = false, const Bunch *next = nullptr) {
+    const int L = e->L, B = e->B, Bp = e->Bp;
     const bool dp = e->comm != nullptr || e->fake_world;  // a 1-rank communicator still takes the exchange path (tests)
     const bool gather = dp && e->dp_mode >= 1;
     const int n_global = B * e->world;
     const float nf = (float)n_global;
     const float inv_n = 1.0f / n_global;  // DevVecMulNum(..., 1.0f/n_frames, ...), BP_GPU.cu:409,423
     const int ML = e->cfg.MLflag;
+    if (e->fake_world) {
+        CHK(fake_world_prepass(e, sample0, nf, inv_n));
+        sample0 += (e->world - 1) * B;  // the last emulated rank runs below
+    }
+    const Bunch bn = bunch_at(e, sample0);
 
     // With the ML loss the hidden activations are sent AFTER the loss kernels: the 257-float all-reduce of the
     // loss statistic uses the same communicator, and collectives of one communicator run one after the other
@@ -712,42 +858,7 @@ static int run_step(mlggd_engine *e, const Bunch &bn, bool prestaged = false, co
         sa = stage_args(e, *next, B, in_bunch_other(e));
         n_stage = stage_blocks(e);
     }
-    {
-        ProfScope ps(e, KC_LOSS, 0);
-        const size_t lds = (size_t)(32 * (Bp + 1) + 32) * sizeof(float);
-        const int n_loss = (e->Dp / 32) * b_tiles;
-        if (ML != 1 && e->loss_fuse) {
-            LossNormArgs la;
-            la.slab = e->slab; la.S = e->S_out; la.bias = e->bias[L - 1]; la.targ = targ_rows;
-            la.B = B; la.D = e->D; la.Dp = e->Dp; la.Bp = Bp; la.beta = e->cfg.shapefactor; la.inv_n = inv_n;
-            la.outT = e->outT; la.eT = e->eT; la.dEdXt = e->dEdXt[L - 1]; la.dEdX = e->dEdX[L - 1];
-            la.b_tiles = b_tiles; la.first = bn.first; la.toff = e->toff;
-            hipLaunchKernelGGL(k_loss_norm, dim3(n_loss + n_stage), dim3(256), 0, e->stream, la, n_loss, sa);
-            CHK(launch_check("k_loss_norm"));
-        } else {
-            LossErrArgs la;
-            la.slab = e->slab; la.S = e->S_out; la.bias = e->bias[L - 1]; la.targ = targ_rows;
-            la.B = B; la.D = e->D; la.Dp = e->Dp; la.Bp = Bp; la.beta = e->cfg.shapefactor; la.want_pow = ML == 1 ? 1 : 0;
-            la.outT = e->outT; la.eT = e->eT; la.pT = e->pT;
-            la.b_tiles = b_tiles; la.first = bn.first; la.toff = e->toff;
-            hipLaunchKernelGGL(k_loss_err, dim3(n_loss + n_stage), dim3(256), 0, e->stream, la, n_loss, sa);
-            CHK(launch_check("k_loss_err"));
-            const float *colsum_in = nullptr;
-            if (dp && ML == 1) {
-                hipLaunchKernelGGL(k_colsum, dim3(e->Dp / 32), dim3(256), lds, e->stream, e->pT, B, Bp, e->colsum);
-                CHK(launch_check("k_colsum"));
-                if (e->fake_world)
-                    hipLaunchKernelGGL(k_scale, dim3(1), dim3(256), 0, e->stream, e->colsum, (size_t)e->Dp, (float)e->world);
-                else
-                    NCCLCHK(g_rccl.AllReduce(e->colsum, e->colsum, (size_t)e->Dp, 7, 0, e->comm, e->stream));
-                colsum_in = e->colsum;
-            }
-            hipLaunchKernelGGL(k_loss_grad, dim3((e->Dp / 32) * b_tiles), dim3(256), lds, e->stream, e->eT, e->pT,
-                               colsum_in, B, e->D, e->Dp, Bp, e->cfg.shapefactor, ML, nf, inv_n, e->scalefactor,
-                               e->dEdXt[L - 1], e->dEdX[L - 1], b_tiles);
-            CHK(launch_check("k_loss_grad"));
-        }
-    }
+    CHK(run_loss(e, bn, nf, inv_n, !dp ? CS_LOCAL : e->fake_world ? CS_GIVEN : CS_ALLREDUCE, false, sa, n_stage));
     if (gather && ML == 1 && L > 2) {
         CHK(gather_begin(e));
         for (int g = 1; g < L - 1; g++) CHK(gather_one(e, e->Y[g], e->Yall[g], (size_t)Bp * e->lsp[g]));
@@ -773,41 +884,21 @@ static int run_step(mlggd_engine *e, const Bunch &bn, bool prestaged = false, co
             CHK(gather_end(e));
             pending_hi = l - 1;
         }
-        if (l != 1) {
-            ProfScope ps(e, KC_DX, l);
-            long long *st = stamps_for(e, KC_DX, l, (Kp / 32) * b_tiles);
-            DxArgs xa = dx_args(e, l);
-            if (e->dx_nw == 8) {
-                const size_t lds = dx_lds_floats<8>() * sizeof(float);
-                CHK(ensure_lds(k_dx<8>, lds));
-                hipLaunchKernelGGL(k_dx<8>, dim3((Kp / 32) * b_tiles), dim3(512), lds, e->stream, xa, st);
-            } else {
-                const size_t lds = dx_lds_floats<4>() * sizeof(float);
-                CHK(ensure_lds(k_dx<4>, lds));
-                hipLaunchKernelGGL(k_dx<4>, dim3((Kp / 32) * b_tiles), dim3(256), lds, e->stream, xa, st);
-            }
-            CHK(launch_check("k_dx"));
-        }
+        if (l != 1) CHK(run_dx(e, l));
         if (two) {  // dw(l) after dX(l): dEdX_l is final and W_l has been read (old weights)
             HIPCHK(hipEventRecord(e->ev_dx[l], e->stream));
             HIPCHK(hipStreamWaitEvent(dws, e->ev_dx[l], 0));
         }
         if (merged) continue;  // all layers' dW + update run as one launch after the last dX
-        {
-            const long tiles128 = (long)((Kp + 127) / 128) * ((Np + 127) / 128);
-            const bool big = e->dw_tile == 0 ? tiles128 >= 192 : e->dw_tile == 2;
-            ProfScope ps(e, KC_DW, l, dws);
-            if (dwp_usable(e))
-                CHK(launch_dwp(e, dwp_jobs(e, l, l, in_rows, nf), !dp, dws, l));
-            else if (big)
-                CHK(launch_dw<2>(e, l, in_rows, !dp, nf, dws));
-            else
-                CHK(launch_dw<1>(e, l, in_rows, !dp, nf, dws));
-        }
+        CHK(launch_dw_layer(e, l, in_rows, !dp, nf, dws));
         if (dp && !gather) {
             HIPCHK(hipEventRecord(e->ev_grad[l], dws));
             HIPCHK(hipStreamWaitEvent(e->comm_stream, e->ev_grad[l], 0));
-            NCCLCHK(g_rccl.AllReduce(e->G[l], e->G[l], (size_t)Kp * Np, 7, 0, e->comm, e->comm_stream));
+            if (e->fake_world) {  // sum over the emulated ranks: what the all-reduce delivers
+                if (e->world > 1) CHK(launch_accum(e->G[l], e->Gpre[l], e->G[l], (size_t)Kp * Np, e->comm_stream));
+            } else {
+                NCCLCHK(g_rccl.AllReduce(e->G[l], e->G[l], (size_t)Kp * Np, 7, 0, e->comm, e->comm_stream));
+            }
             HIPCHK(hipEventRecord(e->ev_red[l], e->comm_stream));
         }
     }
@@ -865,7 +956,11 @@ static int run_step(mlggd_engine *e, const Bunch &bn, bool prestaged = false, co
     if (dp && !gather) {
         // bias gradients were written by the dw kernels; ev_grad[1] is the last of them
         HIPCHK(hipStreamWaitEvent(e->comm_stream, e->ev_grad[1], 0));
-        NCCLCHK(g_rccl.AllReduce(e->gb_all, e->gb_all, e->gb_all_count, 7, 0, e->comm, e->comm_stream));
+        if (e->fake_world) {
+            if (e->world > 1) CHK(launch_accum(e->gb_all, e->gbpre, e->gb_all, e->gb_all_count, e->comm_stream));
+        } else {
+            NCCLCHK(g_rccl.AllReduce(e->gb_all, e->gb_all, e->gb_all_count, 7, 0, e->comm, e->comm_stream));
+        }
         HIPCHK(hipEventRecord(e->ev_bias_red, e->comm_stream));
         for (int l = L - 1; l >= 1; l--) {
             HIPCHK(hipStreamWaitEvent(dws, e->ev_red[l], 0));
@@ -942,6 +1037,7 @@ int mlggd_create(const mlggd_config *cfg, const float *const *weights, const flo
     if (const char *v = getenv("MLGGD_LOSS_FUSE")) e->loss_fuse = atoi(v);
     if (const char *v = getenv("MLGGD_TILE_MAP")) e->tile_map = atoi(v);
     if (const char *v = getenv("MLGGD_STAGE_AHEAD")) e->stage_ahead = atoi(v);
+    if (const char *v = getenv("MLGGD_CV_DEVICE")) e->cv_device = atoi(v) ? 1 : 0;
     *out = e;  // so the caller can destroy on failure
 
     HIPCHK(hipSetDevice(e->device));
@@ -1005,6 +1101,7 @@ int mlggd_destroy(mlggd_handle e) {
     if (e->chunk_in) hipFree(e->chunk_in);
     if (e->chunk_targ) hipFree(e->chunk_targ);
     if (e->chunk_out) hipFree(e->chunk_out);
+    if (e->cv_partial) hipFree(e->cv_partial);
     if (e->copy_stream) hipStreamSynchronize(e->copy_stream);
     for (auto &r : e->raw) {
         if (r.feat) hipFree(r.feat);
@@ -1078,6 +1175,12 @@ int mlggd_set_scalefactor(mlggd_handle e, const float *alpha) {
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipMemcpyAsync(e->scalefactor, alpha, (size_t)e->D * 4, hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
+    return MLGGD_OK;
+}
+
+int mlggd_set_cv_device_reduce(mlggd_handle e, int on) {
+    if (!e) return fail(MLGGD_ERR_ARG, "NULL handle");
+    e->cv_device = on ? 1 : 0;
     return MLGGD_OK;
 }
 
@@ -1220,6 +1323,12 @@ int mlggd_alloc_pinned(size_t bytes, void **out) {
     HIPCHK(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
     return MLGGD_OK;
 }
+int mlggd_alloc_pinned_on(int device, size_t bytes, void **out) {
+    if (!out) return fail(MLGGD_ERR_ARG, "out is NULL");
+    HIPCHK(hipSetDevice(device));  // the calling thread may have no current device yet (a host IO thread)
+    HIPCHK(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    return MLGGD_OK;
+}
 int mlggd_free_pinned(void *p) {
     if (p) HIPCHK(hipHostFree(p));
     return MLGGD_OK;
@@ -1235,11 +1344,13 @@ int mlggd_train_resident(mlggd_handle e, int first_frame, int n_frames, int *bun
     HIPCHK(hipEventRecord(e->ev_t0, e->stream));
     // bunch loop of BP_GPU::train, BP_GPU.cu:170-184: full bunches only
     bool prestaged = false;
-    for (int i = 0; i + e->B <= n_frames; i += e->B) {
-        const bool has_next = e->stage_ahead && i + 2 * e->B <= n_frames;
+    // an emulated world consumes one GLOBAL minibatch of world*B rows per step (and stages nothing ahead)
+    const int per_step = e->fake_world ? e->B * e->world : e->B;
+    for (int i = 0; i + per_step <= n_frames; i += per_step) {
+        const bool has_next = e->stage_ahead && !e->fake_world && i + 2 * e->B <= n_frames;
         Bunch next;
         if (has_next) next = bunch_at(e, first_frame + i + e->B);
-        CHK(run_step(e, bunch_at(e, first_frame + i), prestaged, has_next ? &next : nullptr));
+        CHK(run_step(e, first_frame + i, prestaged, has_next ? &next : nullptr));
         prestaged = has_next;
         trained++;
     }
@@ -1388,9 +1499,62 @@ static int cv_accumulate(mlggd_engine *e, int n_frames, const std::function<cons
     return MLGGD_OK;
 }
 
+// The same three numbers with the sums formed on the device (mlggd_set_cv_device_reduce): one
+// forward pass, k_cv_reduce per bunch, 3 doubles per 32x32 tile copied back -- no n x D transfer and no host
+// loop.  The chunk (inputs AND targets) must be resident.
+static int cv_device_reduce(mlggd_engine *e, int n_frames, float *sqerr, float *abserr, float *loglik) {
+    const int D = e->D, b_tiles = e->Bp / 32, tiles = (e->Dp / 32) * b_tiles;
+    const int nb = (n_frames + e->B - 1) / e->B;
+    const size_t need = (size_t)(nb > 0 ? nb : 1) * tiles * 3;
+    if (need > e->cv_partial_cap) {
+        if (e->cv_partial) hipFree(e->cv_partial);
+        e->cv_partial = nullptr;
+        e->cv_partial_cap = 0;
+        HIPCHK(hipMalloc((void **)&e->cv_partial, need * sizeof(double)));
+        e->cv_partial_cap = need;
+    }
+    // bunch loop of CrossValid*, BP_GPU.cu:202-216: INCLUDES the trailing partial bunch
+    for (int i = 0, k = 0; i < n_frames; i += e->B, k++) {
+        const int fb = (e->B > n_frames - i) ? (n_frames - i) : e->B;
+        const Bunch bn = bunch_at(e, i);
+        CHK(run_forward(e, bn, fb, false));
+        CvArgs a;
+        a.slab = e->slab; a.S = e->S_out; a.bias = e->bias[e->L - 1]; a.targ = bn.targ;
+        a.B = fb; a.D = D; a.Dp = e->Dp; a.Bp = e->Bp; a.beta = e->cfg.shapefactor;
+        a.alpha = loglik ? e->scalefactor : nullptr;
+        a.first = bn.first; a.toff = e->toff; a.b_tiles = b_tiles;
+        a.partial = e->cv_partial + (size_t)k * tiles * 3;
+        hipLaunchKernelGGL(k_cv_reduce, dim3(tiles), dim3(256), 0, e->stream, a);
+        CHK(launch_check("k_cv_reduce"));
+    }
+    std::vector<double> part((size_t)nb * tiles * 3);
+    std::vector<float> scalefac(D);
+    if (nb > 0)
+        HIPCHK(hipMemcpyAsync(part.data(), e->cv_partial, part.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    if (loglik) HIPCHK(hipMemcpyAsync(scalefac.data(), e->scalefactor, (size_t)D * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    double s[3] = {0, 0, 0};
+    for (size_t i = 0; i < part.size(); i += 3)
+        for (int j = 0; j < 3; j++) s[j] += part[i + j];
+    if (sqerr) *sqerr = (float)s[0];
+    if (abserr) *abserr = (float)(s[1] / D);
+    if (loglik) {  // density1 - density2 - density3, BP_GPU.cu:271-301
+        const float beta = e->cfg.shapefactor;
+        const double density1 = (double)n_frames * D * logf(beta / (2 * mlggd_gamma((float)(1.0 / beta))));
+        double density2 = 0;
+        for (int u = 0; u < D; u++) density2 += logf(scalefac[u]);
+        *loglik = (float)(density1 - density2 * n_frames - s[2]);
+    }
+    return MLGGD_OK;
+}
+
 static int cv_metrics(mlggd_engine *e, int n_frames, const float *in, const float *targ, float *sqerr, float *abserr,
                       float *loglik) {
     if (n_frames > 0 && (!in || !targ)) return fail(MLGGD_ERR_ARG, "in/targ is NULL");
+    if (e->cv_device) {
+        CHK(mlggd_load_chunk(e, n_frames, in, targ));
+        return cv_device_reduce(e, n_frames, sqerr, abserr, loglik);
+    }
     CHK(mlggd_load_chunk(e, n_frames, in, nullptr));
     const int D = e->D;
     return cv_accumulate(e, n_frames, [&](int i) { return targ + (size_t)i * D; }, sqerr, abserr, loglik);
@@ -1419,6 +1583,10 @@ int mlggd_cv_all_frames(mlggd_handle e, int n_frames, int fea_context, const flo
                         float *loglik) {
     if (!e) return fail(MLGGD_ERR_ARG, "NULL handle");
     if (n_samples > 0 && !targ) return fail(MLGGD_ERR_ARG, "targ is NULL");
+    if (e->cv_device) {
+        CHK(mlggd_load_frames(e, n_frames, fea_context, feat, targ, n_samples, first_frame, targ_offset));
+        return cv_device_reduce(e, n_samples, sqerr, abserr, (e->cfg.MLflag == 1) ? loglik : nullptr);
+    }
     CHK(mlggd_load_frames(e, n_frames, fea_context, feat, nullptr, n_samples, first_frame, targ_offset));
     const int D = e->D;
     return cv_accumulate(
@@ -1496,6 +1664,25 @@ int mlggd_debug_tensor(mlggd_handle e, const char *name, int layer, float *dst, 
 }
 
 // ---- data parallel
+// gradient buffers (layer_ydedx / layer_sumdedx of BP_WorkSpace) only exist on the all-reduce path
+static int allreduce_alloc(mlggd_engine *e) {
+    size_t gbn = 0;
+    for (int l = 1; l < e->L; l++) gbn += e->lsp[l];
+    CHK(dev_alloc(e, &e->gb_all, gbn));
+    e->gb_all_count = gbn;
+    size_t off = 0;
+    for (int l = e->L - 1; l >= 1; l--) {
+        CHK(dev_alloc(e, &e->G[l], (size_t)e->lsp[l - 1] * e->lsp[l]));
+        e->gb[l] = e->gb_all + off;
+        off += e->lsp[l];
+        HIPCHK(hipEventCreateWithFlags(&e->ev_grad[l], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&e->ev_red[l], hipEventDisableTiming));
+    }
+    HIPCHK(hipEventCreateWithFlags(&e->ev_bias, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&e->ev_bias_red, hipEventDisableTiming));
+    return MLGGD_OK;
+}
+
 int mlggd_comm_unique_id(void *id) {
     if (!id) return fail(MLGGD_ERR_ARG, "id is NULL");
     CHK(rccl_load());
@@ -1537,40 +1724,42 @@ int mlggd_comm_init(mlggd_handle e, const void *id, int world_size, int rank) {
         CHK(gather_alloc(e));
         return e->dp_mode == 2 ? shard_alloc(e) : MLGGD_OK;
     }
-    // gradient buffers (layer_ydedx / layer_sumdedx of BP_WorkSpace) only exist on the all-reduce path
-    size_t gbn = 0;
-    for (int l = 1; l < e->L; l++) gbn += e->lsp[l];
-    CHK(dev_alloc(e, &e->gb_all, gbn));
-    e->gb_all_count = gbn;
-    size_t off = 0;
-    for (int l = e->L - 1; l >= 1; l--) {
-        CHK(dev_alloc(e, &e->G[l], (size_t)e->lsp[l - 1] * e->lsp[l]));
-        e->gb[l] = e->gb_all + off;
-        off += e->lsp[l];
-        HIPCHK(hipEventCreateWithFlags(&e->ev_grad[l], hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&e->ev_red[l], hipEventDisableTiming));
-    }
-    HIPCHK(hipEventCreateWithFlags(&e->ev_bias, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&e->ev_bias_red, hipEventDisableTiming));
-    return MLGGD_OK;
+    return allreduce_alloc(e);
 }
 
-// Test hook: behave like rank 0 of `world_size` ranks that all hold the SAME minibatch, with device copies
-// in place of the collectives (no communicator, one GPU).  The result must equal the single-device step
-// with bunchsize world_size*B on the minibatch repeated world_size times -- the data-parallel contract.
-int mlggd_debug_fake_world(mlggd_handle e, int world_size, int sharded) {
+// Test hook: emulate `world_size` ranks on ONE GPU, without a communicator.  Every training step then
+// consumes one GLOBAL minibatch of world_size*bunchsize rows of the resident chunk; emulated rank r owns rows
+// [r*bunchsize, (r+1)*bunchsize) of it (the partition of SURVEY 8e; different rows on every rank).  The ranks run
+// one after the other (fake_world_prepass, then the real exchange path for the last one) with device copies /
+// adds in place of the RCCL calls.  The result must equal the single-device step with bunchsize
+// world_size*bunchsize on the same rows -- the data-parallel contract.
+// mode: 0 = factor all-gather, replicated update; 1 = factor all-gather, sharded update; 2 = gradient all-reduce.
+int mlggd_debug_fake_world(mlggd_handle e, int world_size, int mode) {
     if (!e) return fail(MLGGD_ERR_ARG, "NULL handle");
     if (e->comm || e->fake_world) return fail(MLGGD_ERR_STATE, "communicator already initialised");
-    if (world_size < 1 || !gather_usable(e, world_size))
+    if (mode < 0 || mode > 2) return fail(MLGGD_ERR_ARG, "mode %d not in 0..2", mode);
+    if (world_size < 1 || (mode != 2 && !gather_usable(e, world_size)))
         return fail(MLGGD_ERR_ARG, "fake world of %d ranks: needs bunchsize %% 32 == 0 and world*bunchsize in {64,...,1024}", world_size);
+    if (e->cfg.dropoutflag == 1 && world_size > 1)
+        return fail(MLGGD_ERR_ARG, "dropout is not supported on the data-parallel path");
     HIPCHK(hipSetDevice(e->device));
     e->world = world_size;
-    e->rank = 0;
+    e->rank = world_size - 1;  // the rank that takes the real exchange path; the others are emulated before it
     e->fake_world = true;
-    e->dp_mode = sharded ? 2 : 1;
+    e->dp_mode = mode == 2 ? 0 : mode == 1 ? 2 : 1;
     HIPCHK(hipStreamCreateWithFlags(&e->comm_stream, hipStreamNonBlocking));
+    CHK(dev_alloc(e, &e->colsum_tot, e->Dp));
+    if (mode == 2) {
+        CHK(allreduce_alloc(e));
+        for (int l = 1; l < e->L; l++) CHK(dev_alloc(e, &e->Gpre[l], (size_t)e->lsp[l - 1] * e->lsp[l]));
+        CHK(dev_alloc(e, &e->gbpre, e->gb_all_count));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        return MLGGD_OK;
+    }
     CHK(gather_alloc(e));
-    return sharded ? shard_alloc(e) : MLGGD_OK;
+    if (mode == 1) CHK(shard_alloc(e));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return MLGGD_OK;
 }
 int mlggd_dp_mode(mlggd_handle e, int *mode) {
     if (!e || !mode) return fail(MLGGD_ERR_ARG, "NULL argument");

@@ -908,6 +908,14 @@ __global__ __launch_bounds__(256) void k_apply_update(float *__restrict__ Wt, fl
     }
 }
 
+// dst = a + b elementwise (a == nullptr: dst = b).  Only the one-GPU emulation of the data-parallel
+// exchange uses it (mlggd_debug_fake_world: the sum over emulated ranks that a collective would form).
+__global__ __launch_bounds__(256) void k_accum(float *__restrict__ dst, const float *a, const float *b, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += stride)
+        dst[idx] = a ? a[idx] + b[idx] : b[idx];
+}
+
 // ---------------------------------------------------------------------------------------
 // Bias update from the all-reduced bias gradients of every layer in one launch
 // (data-parallel path only; on one GPU the bias gradient and update live in k_dw):
@@ -1263,6 +1271,70 @@ __global__ __launch_bounds__(256) void k_out_rowmajor(const float *__restrict__ 
     for (int q = 0; q < 4; q++) {
         const int b = b0 + ty + 8 * q, d = d0 + tx;
         if (b < B && d < D) out[(size_t)b * D + d] = t[tx][ty + 8 * q];
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// CV metrics reduced on the device: per 32(d) x 32(b) tile of one CV bunch the three sums
+// that CrossValid / CrossValiddB / CrossValid2 accumulate on the host (BP_GPU.cu:207-213, 240-250, 293-298):
+//   sum (o-t)^2,   sum |o-t|,   sum (|t-o| / alpha_d)^beta
+// Every term is formed in fp32 exactly as the host loops form it; the SUMS are kept in double (a tree over
+// the tile, one double triple per tile, tiles and bunches combined on the host in double), so this path does
+// not reproduce the reference's fp32 frame-major accumulation order -- the host-order path stays the default
+// for the log lines.  Nothing of size n x D leaves the device.
+// ---------------------------------------------------------------------------------------
+struct CvArgs {
+    const float *slab;
+    int S;
+    const float *bias, *targ;
+    int B, D, Dp, Bp;
+    float beta;
+    const float *alpha;  // scalefactor [D]; nullptr: no likelihood term
+    const int *first;
+    int toff, b_tiles;
+    double *partial;     // [tiles][3] of this bunch
+};
+__global__ __launch_bounds__(256) void k_cv_reduce(CvArgs A) {
+    __shared__ float tt[32][33];
+    __shared__ double red[4][3];
+    const int dt = blockIdx.x / A.b_tiles, bt = blockIdx.x % A.b_tiles;
+    const int d0 = dt * 32, b0 = bt * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int b = b0 + ty + 8 * q, d = d0 + tx;
+        tt[ty + 8 * q][tx] = (b < A.B && d < A.D) ? A.targ[(size_t)(A.first ? A.first[b] + A.toff : b) * A.D + d] : 0.0f;
+    }
+    __syncthreads();
+    double sq = 0.0, ab = 0.0, ll = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int dl = ty + 8 * q, d = d0 + dl, b = b0 + tx;
+        if (b < A.B && d < A.D) {
+            float x = slab_sum(A.slab, (size_t)d * A.Bp + b, (size_t)A.Dp * A.Bp, A.S);
+            x = x + A.bias[d];
+            const float t = tt[tx][dl];
+            sq += (double)((x - t) * (x - t));   // BP_GPU.cu:211
+            ab += (double)fabsf(x - t);           // BP_GPU.cu:246
+            if (A.alpha) ll += (double)powf(fabsf(t - x) / A.alpha[d], A.beta);  // BP_GPU.cu:295-296
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        sq += __shfl_down(sq, off, 64);
+        ab += __shfl_down(ab, off, 64);
+        ll += __shfl_down(ll, off, 64);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        red[wave][0] = sq;
+        red[wave][1] = ab;
+        red[wave][2] = ll;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int j = threadIdx.x;
+        A.partial[(size_t)blockIdx.x * 3 + j] = ((red[0][j] + red[1][j]) + red[2][j]) + red[3][j];
     }
 }
 

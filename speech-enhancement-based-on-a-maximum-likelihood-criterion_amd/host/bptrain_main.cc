@@ -30,6 +30,7 @@
 #include <unistd.h>
 
 #include "bp_gpu.h"
+#include "dp_launch.h"
 #include "trainer_io.h"
 
 using mlggd_host::Interface;
@@ -73,9 +74,11 @@ void swap_buffers(Interface *io, bool frames) {  // BPtrain.cc:25-32
 
 // threadFetch, BPtrain.cc:15-54
 std::atomic<bool> g_stop_fetch{false};  // set when the trainer gives up before consuming every chunk
+int g_pinned_device = 0;                // device whose context owns the page-locked chunk buffers
 
 void fetch_loop(Interface *io, Slot *slot, std::string *error, bool frames) {
     try {
+        if (frames) io->reserve_frame_buffers(io->train_plan);  // once, for the largest chunk: no re-allocation mid-epoch
         for (unsigned i = 0; i < io->total_chunks && !g_stop_fetch; i++) {
             const int n = frames ? io->Readchunk_frames(io->chunk_index[i]) : io->Readchunk(io->chunk_index[i]);
             if (i > 0) slot->wait(false);                      // trainer done with indata[1]
@@ -96,29 +99,13 @@ int env_int(const char *name, int dflt) {
     return v && *v ? atoi(v) : dflt;
 }
 
-// rank 0 writes the RCCL id to MLGGD_ID_FILE (atomically, via rename); the others poll for it
-void exchange_id(int rank, unsigned char id[MLGGD_UNIQUE_ID_BYTES]) {
+// rank 0 creates the RCCL id and hands it to the other ranks through MLGGD_ID_FILE (dp_launch.h: a handshake
+// with per-launch nonces, so a file left by an earlier epoch's launch is never accepted)
+void exchange_id(int world, int rank, unsigned char id[MLGGD_UNIQUE_ID_BYTES]) {
+    static_assert(MLGGD_UNIQUE_ID_BYTES == mlggd_host::kUniqueIdBytes, "id size");
     const char *path = getenv("MLGGD_ID_FILE");
-    if (!path || !*path) throw IoError("WORLD_SIZE > 1 needs MLGGD_ID_FILE (path visible to every rank)");
-    if (rank == 0) {
-        if (mlggd_comm_unique_id(id) != MLGGD_OK) throw IoError(mlggd_last_error());
-        const std::string tmp = std::string(path) + ".tmp";
-        FILE *fp = fopen(tmp.c_str(), "wb");
-        if (!fp || fwrite(id, 1, MLGGD_UNIQUE_ID_BYTES, fp) != MLGGD_UNIQUE_ID_BYTES) throw IoError("cannot write MLGGD_ID_FILE");
-        fclose(fp);
-        if (rename(tmp.c_str(), path) != 0) throw IoError("cannot publish MLGGD_ID_FILE");
-    } else {
-        for (int tries = 0; tries < 6000; tries++) {
-            FILE *fp = fopen(path, "rb");
-            if (fp) {
-                const size_t n = fread(id, 1, MLGGD_UNIQUE_ID_BYTES, fp);
-                fclose(fp);
-                if (n == MLGGD_UNIQUE_ID_BYTES) return;
-            }
-            usleep(10000);
-        }
-        throw IoError("timed out waiting for MLGGD_ID_FILE");
-    }
+    if (rank == 0 && mlggd_comm_unique_id(id) != MLGGD_OK) throw IoError(mlggd_last_error());
+    mlggd_host::rendezvous(path ? path : "", world, rank, id, (double)env_int("MLGGD_RENDEZVOUS_TIMEOUT", 600));
 }
 
 }  // namespace
@@ -161,11 +148,19 @@ int main(int argc, char *argv[]) {
         const bool frames = env_int("MLGGD_EXPANDED", 0) == 0;
         // page-locked chunk buffers: the per-chunk upload of ~200 MB runs at DMA speed instead of through
         // the runtime's staging copies
+        // (allocated by the fetch thread, which has no current device of its own: the allocator names this
+        // rank's device, so no rank pins its buffers through GPU 0's context)
+        const int device = world > 1 ? local_rank : p->gpu_used;
+        g_pinned_device = device;
         if (frames && env_int("MLGGD_PINNED", 1))
             io->set_buffer_allocator(
                 [](size_t n) -> void * {
                     void *q = nullptr;
-                    return mlggd_alloc_pinned(n, &q) == MLGGD_OK ? q : nullptr;
+                    if (mlggd_alloc_pinned_on(g_pinned_device, n, &q) != MLGGD_OK) {
+                        fprintf(stderr, "page-locked chunk buffer of %zu bytes: %s\n", n, mlggd_last_error());
+                        return nullptr;
+                    }
+                    return q;
                 },
                 [](void *q) { mlggd_free_pinned(q); });
         std::thread fetch(fetch_loop, io, &slot, &fetch_error, frames);
@@ -182,14 +177,14 @@ int main(int argc, char *argv[]) {
         } fetch_guard{fetch, slot};
         phase("pfile headers, chunk plan", t_phase);
 
-        const int device = world > 1 ? local_rank : p->gpu_used;
         BP_GPU *net = new BP_GPU(p->init_randem_seed, device, io->numlayers, p->layersizes, p->bunchsize, p->lrate,
                                  p->momentum, p->weightcost, p->weights, p->bias, p->shapefactor, p->MLflag,
                                  p->dropoutflag, p->visible_omit, p->hid_omit);
         if (world > 1) {
             unsigned char id[MLGGD_UNIQUE_ID_BYTES];
-            exchange_id(rank, id);
-            net->joinComm(id, world, rank);
+            exchange_id(world, rank, id);
+            net->joinComm(id, world, rank);  // collective: returns once every rank has joined
+            if (rank == 0) mlggd_host::rendezvous_cleanup(getenv("MLGGD_ID_FILE"), world);
         }
         phase("engine (HIP init, upload)", t_phase);
         const int K0 = p->layersizes[0], D = p->layersizes[io->numlayers - 1], B = p->bunchsize;
@@ -205,12 +200,11 @@ int main(int argc, char *argv[]) {
                 std::vector<int> loc_first;
                 int nloc = ns;
                 if (world > 1) {  // this rank's rows of every complete global minibatch
-                    const int gb = B * world, nglob = ns / gb;
-                    loc_first.resize((size_t)nglob * B);
-                    for (int g = 0; g < nglob; g++)
-                        memcpy(&loc_first[(size_t)g * B], first + (size_t)g * gb + (size_t)rank * B, (size_t)B * sizeof(int));
+                    const std::vector<int> rows = mlggd_host::rank_sample_rows(ns, B, world, rank);
+                    loc_first.resize(rows.size());
+                    for (size_t j = 0; j < rows.size(); j++) loc_first[j] = first[rows[j]];
                     first = loc_first.data();
-                    nloc = nglob * B;
+                    nloc = (int)rows.size();
                 }
                 // no wait: the buffers are free once the chunk is on the device, and the next chunk's upload
                 // overlaps these steps (the engine keeps two device buffer sets)
@@ -220,15 +214,14 @@ int main(int argc, char *argv[]) {
                 net->train(ns, p->indata[1], p->targ[1]);
             } else {
                 // this rank's rows of every complete global minibatch, compacted
-                const int gb = B * world, nglob = ns / gb;
-                loc_in.resize((size_t)nglob * B * K0);
-                loc_targ.resize((size_t)nglob * B * D);
-                for (int g = 0; g < nglob; g++) {
-                    const size_t src = (size_t)g * gb + (size_t)rank * B;
-                    memcpy(&loc_in[(size_t)g * B * K0], p->indata[1] + src * K0, (size_t)B * K0 * sizeof(float));
-                    memcpy(&loc_targ[(size_t)g * B * D], p->targ[1] + src * D, (size_t)B * D * sizeof(float));
+                const std::vector<int> rows = mlggd_host::rank_sample_rows(ns, B, world, rank);
+                loc_in.resize(rows.size() * K0);
+                loc_targ.resize(rows.size() * D);
+                for (size_t j = 0; j < rows.size(); j++) {
+                    memcpy(&loc_in[j * K0], p->indata[1] + (size_t)rows[j] * K0, (size_t)K0 * sizeof(float));
+                    memcpy(&loc_targ[j * D], p->targ[1] + (size_t)rows[j] * D, (size_t)D * sizeof(float));
                 }
-                net->train(nglob * B, loc_in.data(), loc_targ.data());
+                net->train((int)rows.size(), loc_in.data(), loc_targ.data());
             }
             slot.set(false);
         }
@@ -255,6 +248,7 @@ int main(int argc, char *argv[]) {
                 float sq = 0, ab = 0, ll = 0;
                 int n;
                 if (frames) {
+                    if (i == 0) io->reserve_frame_buffers(io->cv_plan);  // the device is idle here (net->sync() above)
                     n = io->Readchunk_frames_cv((int)i);
                     net->CrossValidAll_frames(p->chunk_frames[0], p->fea_context, p->frames_in[0], p->frames_targ[0], n,
                                               p->first_frame[0], p->targ_offset, &sq, &ab, &ll);

@@ -5,6 +5,7 @@
 #include <string>
 #include <vector>
 
+#include "dp_launch.h"
 #include "trainer_io.h"
 
 using namespace mlggd_host;
@@ -117,5 +118,25 @@ int mlggd_host_write_pfile(const char *path, const int *sent_lengths, int nsent,
         return -1;
     }
 }
+
+// data-parallel launch helpers (dp_launch.h)
+int mlggd_host_rank_rows(int n_samples, int bunch, int world, int rank, int *rows, int cap) {
+    const std::vector<int> r = rank_sample_rows(n_samples, bunch, world, rank);
+    for (size_t i = 0; i < r.size() && (int)i < cap; i++) rows[i] = r[i];
+    return (int)r.size();
+}
+
+// 0 on success, -1 on error / timeout (message in mlggd_host_last_error)
+int mlggd_host_rendezvous(const char *path, int world, int rank, unsigned char *id, double timeout_s) {
+    try {
+        rendezvous(path ? path : "", world, rank, id, timeout_s);
+        return 0;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
+void mlggd_host_rendezvous_cleanup(const char *path, int world) { rendezvous_cleanup(path, world); }
 
 }  // extern "C"

@@ -109,6 +109,22 @@ void *Interface::ensure(HostBuf &b, size_t bytes) {
     return b.p;
 }
 
+void Interface::reserve_frame_buffers(const ChunkPlan &plan) {
+    const WorkPara &p = *para;
+    int max_frames = 0;
+    for (unsigned i = 0; i < plan.total_chunks; i++) {
+        const bool last = i + 1 == plan.total_chunks;
+        const int frames = (last ? framesBeforeSent[plan.sent_en] : plan.frame_st[i + 1]) - plan.frame_st[i];
+        if (frames > max_frames) max_frames = frames;
+    }
+    const size_t samples = plan.total_chunks > 1 ? (size_t)p.traincache : (size_t)plan.total_samples;
+    for (int s = 0; s < 2; s++) {
+        ensure(fr_in_[s], (size_t)max_frames * p.fea_dim * sizeof(float));
+        ensure(fr_targ_[s], (size_t)max_frames * p.layersizes[numlayers - 1] * sizeof(float));
+        ensure(fr_first_[s], (samples > 0 ? samples : 1) * sizeof(int));
+    }
+}
+
 Interface::~Interface() {
     for (Mapping *m : {&map_data_, &map_targ_})
         if (m->base) munmap(const_cast<unsigned char *>(m->base), m->size);

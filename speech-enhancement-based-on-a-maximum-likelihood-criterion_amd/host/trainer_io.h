@@ -74,6 +74,10 @@ class Interface {
     void want_expanded_buffers();
     // call after handing slot 0 of the frame-stream buffers to the consumer (pointer swap 0<->1)
     void frames_swapped() { fr_fill_ ^= 1; }
+    // Sizes both sets of frame-stream chunk buffers for the LARGEST chunk of `plan`, so that no buffer is
+    // re-allocated while chunks of that plan are being trained (re-allocating page-locked memory synchronises
+    // the device).  Call after get_chunk_info[_cv], before the first Readchunk_frames[_cv] of the plan.
+    void reserve_frame_buffers(const ChunkPlan &plan);
     // allocator of the frame-stream chunk buffers (default malloc/free); set before the first Readchunk_frames
     void set_buffer_allocator(void *(*alloc)(size_t), void (*release)(void *)) {
         buf_alloc_ = alloc;

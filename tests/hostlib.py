@@ -30,6 +30,9 @@ def lib():
         L.mlggd_host_shuffle.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int]
         L.mlggd_host_weights.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.mlggd_host_write_pfile.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(C.c_float)]
+        L.mlggd_host_rank_rows.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]
+        L.mlggd_host_rendezvous.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_ubyte), C.c_double]
+        L.mlggd_host_rendezvous_cleanup.argtypes = [C.c_char_p, C.c_int]
         _lib = L
     return _lib
 
@@ -242,3 +245,19 @@ class HostNorm:
         mean = np.array([float(x) for x in lines[1:1 + dim]], np.float32)
         inv = np.array([float(x) for x in lines[2 + dim:2 + 2 * dim]], np.float32)
         return mean, inv
+
+
+def rank_rows(n_samples, bunch, world, rank):
+    """dp_launch.h rank_sample_rows: the sample rows of a chunk that `rank` trains, in training order."""
+    cap = max(n_samples, 1)
+    buf = (C.c_int * cap)()
+    n = lib().mlggd_host_rank_rows(n_samples, bunch, world, rank, buf, cap)
+    return np.array(buf[:n], np.int64)
+
+
+def rendezvous(path, world, rank, ident=None, timeout=20.0):
+    """dp_launch.h rendezvous: rank 0 passes the 128-byte id in, the others get it back."""
+    buf = (C.c_ubyte * 128)(*(ident if ident is not None else bytes(128)))
+    if lib().mlggd_host_rendezvous(str(path).encode(), world, rank, buf, float(timeout)) != 0:
+        raise HostError(lib().mlggd_host_last_error().decode())
+    return bytes(buf)

@@ -99,29 +99,32 @@ def test_exchange_path_on_one_rank_communicator(pkg, pyoracle, synth, monkeypatc
     eng.close()
 
 
-@pytest.mark.parametrize("sharded", [False, True])
-@pytest.mark.parametrize("world,B", [(2, 64), (2, 128), (4, 128), (8, 128), (4, 32)])
+@pytest.mark.parametrize("mode", ["gather", "shard", "allreduce"])
+@pytest.mark.parametrize("world,B", [(2, 64), (2, 128), (4, 128), (8, 128), (4, 32), (3, 50)])
 @pytest.mark.parametrize("ml,beta", [(0, 2.0), (1, 1.2)])
-def test_gather_exchange_equals_one_device_with_the_global_bunch(pkg, pyoracle, synth, ml, beta, world, B, sharded):
-    """SURVEY 8e parity definition: n ranks x B frames == one device with bunchsize n*B on the same
-    frame order.  `world` identical ranks are emulated on one GPU (device copies instead of RCCL), so
-    the global minibatch is the local one repeated `world` times; the oracle trains exactly that with
-    bunchsize world*B.  Covers the dW kernel over 2..16 units of 64 gathered frames.  sharded: every
-    emulated rank updates only its block of weight rows (all of them run in turn on this GPU, the bias
-    update comes from the last rank's bias-only jobs); layer sizes give uneven and empty blocks."""
+def test_emulated_world_equals_one_device_with_the_global_bunch(pkg, pyoracle, synth, ml, beta, world, B, mode):
+    """SURVEY 8e parity definition: n ranks x B frames == one device with bunchsize n*B on the same frame
+    order.  `world` ranks are emulated on one GPU, one after the other, each on ITS OWN rows
+    [r*B,(r+1)*B) of every global minibatch (mlggd_debug_fake_world: device copies / adds in place of the
+    RCCL calls); the oracle trains the same rows with bunchsize world*B.
+    gather / shard: the rank-major row order of the gathered factors, the dW kernel over 2..16 units of 64
+    gathered frames, the global 1/n and the ML statistic summed over ranks; shard: every emulated rank
+    updates only its block of weight rows (uneven and empty blocks included), the bias update comes from
+    the last rank's bias-only jobs.  allreduce: k_dwp<.,false> -> sum of the ranks' gradients ->
+    k_apply_update / k_bias_apply with n_global != B (any shape, e.g. 3 x 50)."""
+    if mode != "allreduce" and (B % 32 or world * B not in (64, 128, 256, 512, 1024)):
+        pytest.skip("factor exchange needs world*B in {64,...,1024}")
     ls = [40 * 5, 160, 96, 40]
     ws, bs = synth.make_weights(ls, seed=8)
     rng = np.random.default_rng(9)
     bs = [rng.uniform(-0.1, 0.1, b.shape).astype(np.float32) for b in bs]
     steps = 2
-    inp, targ = synth.make_frames(steps * B, 40, 5, seed=10)
+    inp, targ = synth.make_frames(steps * world * B + 5, 40, 5, seed=10)   # + a ragged tail that is ignored
     eng = pkg.BPGpu(1, 0, ls, B, *HP, ws, bs, beta, ml)
-    eng.fake_world(world, sharded)
-    assert eng.dp_mode() == (3 if sharded else 2)
+    eng.fake_world(world, sharded=mode == "shard", allreduce=mode == "allreduce")
+    assert eng.dp_mode() == {"allreduce": 1, "gather": 2, "shard": 3}[mode]
     ora = pyoracle.OracleNet(ls, world * B, *HP, beta, ml, ws, bs)
-    gi = np.concatenate([np.tile(inp[s * B:(s + 1) * B], (world, 1)) for s in range(steps)])
-    gt = np.concatenate([np.tile(targ[s * B:(s + 1) * B], (world, 1)) for s in range(steps)])
-    assert eng.train(inp, targ) == steps and ora.train(gi, gt) == steps
+    assert eng.train(inp, targ) == steps and ora.train(inp, targ) == steps
     we, be = eng.returnWeights()
     wo, bo = ora.get_weights()
     for l in range(len(we)):
@@ -129,6 +132,8 @@ def test_gather_exchange_equals_one_device_with_the_global_bunch(pkg, pyoracle, 
         assert relmax(be[l], bo[l]) < 2e-5, l
         assert relmax(eng.debug_tensor("delta_w", l + 1), ora.tensor("delta_w", l + 1)) < 2e-4, l
         assert relmax(eng.debug_tensor("delta_b", l + 1), ora.tensor("delta_b", l + 1)) < 2e-4, l
+        if mode == "allreduce":
+            assert relmax(eng.debug_tensor("grad_w", l + 1), ora.tensor("grad_w", l + 1)) < 3e-4, l
     if ml:
         assert relmax(eng.scalefactor(), ora.tensor("scalefactor")) < 1e-5
     eng.close()

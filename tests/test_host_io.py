@@ -228,3 +228,63 @@ def test_reference_sample_pfiles(tmp_path):
     io = io_for(7, 512)
     assert io.plan("0-7") == ([0, 530, 1066], 1431)
     io.close()
+
+
+def test_rank_rows_are_the_global_minibatch_partition():
+    """bptrain_main's per-rank slicing (dp_launch.h): rank r trains rows [r*B,(r+1)*B) of every COMPLETE global
+    minibatch of world*B samples -- the partition the emulated-world GPU tests and SURVEY 8e use -- and the
+    ranks together cover each global minibatch exactly once, in order; the ragged tail belongs to nobody."""
+    for ns, B, world in ((1000, 16, 4), (1024, 128, 8), (130, 128, 2), (5, 8, 2), (96, 32, 3)):
+        per_rank = [hostlib.rank_rows(ns, B, world, r) for r in range(world)]
+        nglob = ns // (B * world)
+        for r, rows in enumerate(per_rank):
+            want = (np.arange(nglob)[:, None] * B * world + r * B + np.arange(B)[None, :]).ravel()
+            assert np.array_equal(rows, want)
+        if nglob:
+            # rank-major concatenation of step g == rows [g*W*B, (g+1)*W*B): what the gathered factor buffers hold
+            for g in range(nglob):
+                cat = np.concatenate([rows[g * B:(g + 1) * B] for rows in per_rank])
+                assert np.array_equal(cat, np.arange(g * B * world, (g + 1) * B * world))
+    assert len(hostlib.rank_rows(100, 16, 4, 4)) == 0     # rank out of range: nothing
+
+
+def test_rendezvous_never_accepts_a_stale_id_file(tmp_path):
+    """finetune.pl starts one BPtrain_Sigmoid launch per epoch, so MLGGD_ID_FILE from the previous
+    epoch (or a crashed launch: id, go and ack files all present) is already there when the ranks of the next
+    launch start.  Ranks 1..3 start BEFORE rank 0, see the complete stale set, and must still come out with
+    the NEW id; afterwards rank 0's cleanup leaves nothing behind."""
+    import struct
+    import threading
+    import time
+    path = tmp_path / "rccl.id"
+    world = 4
+    stale_id, new_id = bytes([7] * 128), bytes(range(128))
+    # a complete, well-formed set of files from an "earlier launch" with nonce 0x1111 and M_r = 0x2220 + r
+    open(path, "wb").write(b"MLGGDID2" + struct.pack("<Q", 0x1111) + stale_id)
+    open(str(path) + ".go", "wb").write(struct.pack("<4Q", 0x1111, 0x2221, 0x2222, 0x2223))
+    for r in range(1, world):
+        open("%s.ack.%d" % (path, r), "wb").write(struct.pack("<2Q", 0x1111, 0x2220 + r))
+    got, errs = {}, []
+
+    def run(rank, ident):
+        try:
+            got[rank] = hostlib.rendezvous(path, world, rank, ident)
+        except Exception as e:  # noqa: BLE001
+            errs.append((rank, e))
+
+    others = [threading.Thread(target=run, args=(r, None)) for r in range(1, world)]
+    for t in others:
+        t.start()
+    time.sleep(0.3)                       # the other ranks are polling the stale files now
+    assert not got                        # ... and none of them has accepted the stale id
+    t0 = threading.Thread(target=run, args=(0, new_id))
+    t0.start()
+    for t in others + [t0]:
+        t.join(30)
+    assert not errs, errs
+    assert all(got[r] == new_id for r in range(world))
+    hostlib.lib().mlggd_host_rendezvous_cleanup(str(path).encode(), world)
+    assert [f for f in os.listdir(tmp_path)] == []
+    # a rank whose peers never show up gives up with a message instead of hanging
+    with pytest.raises(hostlib.HostError, match="timed out"):
+        hostlib.rendezvous(path, 2, 1, None, timeout=0.2)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Compute-side cost of the data-parallel step on ONE GPU: `world` identical ranks are emulated (device
-copies instead of RCCL), so this shows what the gather exchange costs in kernels -- the dW kernel over the
-global minibatch -- not what the links cost."""
+"""Compute-side cost of the data-parallel step on ONE GPU: `world` ranks are emulated one after the other
+(device copies instead of RCCL), so only the dW launch over the gathered global minibatch is timed here --
+what the factor exchange costs in kernels on ONE rank, not what the links cost."""
 import importlib, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -18,10 +18,7 @@ for world, sharded in ((1, False), (2, False), (4, False), (8, False), (8, True)
         eng.fake_world(world, sharded)
     eng.load_chunk(inp, targ)
     eng.train_resident(0, NB * B); eng.sync()
-    t0 = time.perf_counter()
-    for _ in range(8): eng.train_resident(0, NB * B)
-    eng.sync(); dt = (time.perf_counter() - t0) / (8 * NB)
     eng.profile_select("dw", 0, 4096); eng.train_resident(0, NB * B); us, n = eng.profile_read(); eng.profile_select(None)
-    print("world %d%s: %.1f us/step with the emulated exchange (device copies); dW launch %.1f us incl. ~3.8 us bracket"
-          % (world, " sharded update (rank 3's share only; W all-gather not emulated)" if sharded else "", dt * 1e6, us), flush=True)
+    print("world %d%s: dW launch over %d gathered frames %.1f us incl. ~3.8 us bracket (%d launches)"
+          % (world, " sharded update (rank 3's share only; W all-gather not emulated)" if sharded else "", world * B, us, n), flush=True)
     eng.close()

@@ -34,30 +34,28 @@ for case in range(N):
         cands = [w for w in (2, 4, 8) if w * B in (64, 128, 256, 512, 1024)]
         if cands:
             world = int(rng.choice(cands))
-    sharded = bool(world > 1 and rng.random() < 0.5)
+    dp = ['gather', 'shard', 'allreduce'][int(rng.integers(0, 3))] if world > 1 else ''
     frames_mode = bool(world == 1 and rng.random() < 0.4)
     ws, bs = synth.make_weights(ls, seed=100 + case)
     bs = [rng.uniform(-0.1, 0.1, b.shape).astype(np.float32) for b in bs]
-    nfr = steps * B + ctx + 40
+    nfr = steps * world * B + ctx + 40
     feat = rng.standard_normal((nfr, dim), dtype=np.float32)
     targ_fr = (0.5 * feat + 0.5 * rng.standard_normal((nfr, dim), dtype=np.float32)).astype(np.float32)
-    first = rng.permutation(nfr - ctx + 1)[:steps * B + int(rng.integers(0, 5))].astype(np.int32)
+    first = rng.permutation(nfr - ctx + 1)[:steps * world * B + int(rng.integers(0, 5))].astype(np.int32)
     toff = int(rng.integers(0, ctx))
-    steps = len(first) // B  # a small B turns the ragged tail into extra full bunches
+    steps = len(first) // (world * B)  # a small B turns the ragged tail into extra full bunches
     idx = first[:, None] + np.arange(ctx)[None, :]
     inp = np.ascontiguousarray(feat[idx].reshape(len(first), ctx * dim))
     tg = np.ascontiguousarray(targ_fr[first + toff])
     eng = pkg.BPGpu(1, 0, ls, B, *HP, ws, bs, beta, ml)
     if world > 1:
-        eng.fake_world(world, sharded)
+        eng.fake_world(world, sharded=dp == 'shard', allreduce=dp == 'allreduce')  # rank r: rows [r*B,(r+1)*B) of each global minibatch
     ora = pyoracle.OracleNet(ls, world * B, *HP, beta, ml, ws, bs)
     if frames_mode:
         got = eng.train_frames(feat, targ_fr, first, ctx, toff)
     else:
         got = eng.train(inp, tg)
-    gi = np.concatenate([np.tile(inp[s * B:(s + 1) * B], (world, 1)) for s in range(steps)]) if world > 1 else inp
-    gt = np.concatenate([np.tile(tg[s * B:(s + 1) * B], (world, 1)) for s in range(steps)]) if world > 1 else tg
-    exp = ora.train(gi, gt)
+    exp = ora.train(inp, tg)  # one device, bunchsize world*B, the same rows
     assert got == steps and exp == steps, (got, exp, steps)
     we, be = eng.returnWeights(); wo, bo = ora.get_weights()
     err = max(max(relmax(a, b) for a, b in zip(we, wo)), max(relmax(a, b) for a, b in zip(be, bo)))
@@ -66,7 +64,7 @@ for case in range(N):
     tol = 2e-5 if B >= 7 else 2e-4
     tag = "ok " if err < tol else "BAD"
     print("%s case %2d: layers %-28s B %3d  loss (%d,%.1f) steps %d world %d%s%s  err %.1e" %
-          (tag, case, ls, B, ml, beta, steps, world, " sharded" if sharded else "", " frames" if frames_mode else "", err),
+          (tag, case, ls, B, ml, beta, steps, world, " " + dp if dp else "", " frames" if frames_mode else "", err),
           flush=True)
     assert err < tol
     eng.close(); ora.close()
