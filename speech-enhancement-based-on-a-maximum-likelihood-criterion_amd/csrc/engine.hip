@@ -5,6 +5,7 @@
 // accumulation and weight read-back -- re-designed for one HIP stream of fused gfx950 kernels
 // (kernels.hip.h) instead of ~50 launches + cuBLAS on two racing streams.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <dlfcn.h>
 #include <math.h>
@@ -181,6 +182,8 @@ struct mlggd_engine {
     int prof_class = -1, prof_layer = 0, prof_stride = 1;
     std::vector<hipEvent_t> prof_ev;
     size_t prof_used = 0;
+    hipEvent_t *prof_attach = nullptr;  // event pair waiting to be attached to the next dW launch
+    bool prof_attached = false;
     double prof_flops = 0, prof_bytes = 0;
 
     // diagnostic in-kernel phase stamps (one launch of one (class, layer))
@@ -223,25 +226,47 @@ static int download_padded(float *dst, const float *src, int Np, int K, int N, h
 }
 
 // ------------------------------------------------------------------ kernel launch plan
+// Times the launches of one kernel class with a pair of HIP events per launch (mlggd_profile_select).
+// The weight-gradient kernels (class "dw") take the pair INTO the launch (hipExtLaunchKernelGGL start / stop
+// events = the dispatch's own begin / end timestamps, what rocprofv3 reports as the kernel's duration); the other
+// classes are bracketed by events recorded on the stream before and after, which adds the cost of the bracket.
 struct ProfScope {
     mlggd_engine *e;
     hipStream_t st;
-    bool on;
+    bool on, attach;
     ProfScope(mlggd_engine *eng, int cls, int layer, hipStream_t s = nullptr)
-        : e(eng), st(s ? s : eng->stream), on(false) {
+        : e(eng), st(s ? s : eng->stream), on(false), attach(cls == KC_DW) {
         if (e->prof_class == cls && (e->prof_layer == 0 || e->prof_layer == layer) &&
             e->step_counter % (unsigned)e->prof_stride == 0 && e->prof_used + 2 <= e->prof_ev.size()) {
             on = true;
-            hipEventRecord(e->prof_ev[e->prof_used], st);
+            if (attach) {
+                e->prof_attach = &e->prof_ev[e->prof_used];  // consumed by the launch itself
+                e->prof_attached = false;
+            } else if (hipEventRecord(e->prof_ev[e->prof_used], st) != hipSuccess) {
+                on = false;
+            }
         }
     }
     ~ProfScope() {
-        if (on) {
-            hipEventRecord(e->prof_ev[e->prof_used + 1], st);
+        if (!on) return;
+        if (attach) {
+            e->prof_attach = nullptr;
+            if (e->prof_attached) e->prof_used += 2;
+        } else if (hipEventRecord(e->prof_ev[e->prof_used + 1], st) == hipSuccess) {
             e->prof_used += 2;
         }
     }
 };
+// launch a dW kernel, with the pending event pair of the profiler attached if there is one
+template <typename F, typename... Args>
+static void launch_timed(mlggd_engine *e, F kernel, dim3 grid, dim3 block, size_t lds, hipStream_t st, Args... args) {
+    if (e->prof_attach && !e->prof_attached) {
+        hipExtLaunchKernelGGL(kernel, grid, block, (std::uint32_t)lds, st, e->prof_attach[0], e->prof_attach[1], 0u, args...);
+        e->prof_attached = true;
+    } else {
+        hipLaunchKernelGGL(kernel, grid, block, lds, st, args...);
+    }
+}
 
 static int launch_check(const char *what) {
     hipError_t err = hipGetLastError();
@@ -307,7 +332,7 @@ static DwpArgs dwp_args(mlggd_engine *e, int l, const float *in_rows, const floa
     a.bias = e->bias[l];
     a.dbias = e->dbias[l];
     a.gb = e->gb[l];
-    a.ldA = (l == 1) ? e->K0 : Kp;
+    a.ldA = Kp;  // layer 1 reads the staged, padded copy of the minibatch's rows (in_bunch), not the caller's chunk
     a.K = e->ls[l - 1];
     a.N = e->ls[l];
     a.Kp = Kp;
@@ -344,8 +369,9 @@ static Bunch bunch_at(mlggd_engine *e, int sample) {
     }
     return b;
 }
-// row-major [frames][K0] view of the bunch for the layer-1 dW operand / dropout
-static const float *bunch_rows(mlggd_engine *e, const Bunch &b) { return b.first ? e->in_bunch : b.in; }
+// row-major [Bp][lsp[0]] copy of the bunch (16-byte aligned rows, zero pads) written by the input-staging kernel:
+// the layer-1 dW operand, the data-parallel input factor and what dropout masks
+static const float *bunch_rows(mlggd_engine *e, const Bunch &) { return e->in_bunch; }
 
 static StageArgs stage_args(mlggd_engine *e, const Bunch &bn, int frames, float *rows_out) {
     StageArgs a;
@@ -353,12 +379,13 @@ static StageArgs stage_args(mlggd_engine *e, const Bunch &bn, int frames, float 
     a.ld = e->K0;
     a.B = frames;
     a.K = e->K0;
+    a.Kp = e->lsp[0];
     a.inT = e->Yt[0];
     a.Bp = e->Bp;
     a.b_tiles = e->Bp / 32;
     a.first = bn.first;
     a.fdim = e->fdim;
-    a.rows_out = bn.first ? rows_out : nullptr;
+    a.rows_out = rows_out;
     return a;
 }
 static int stage_blocks(const mlggd_engine *e) { return (e->lsp[0] / 32) * (e->Bp / 32); }
@@ -389,7 +416,7 @@ static int run_dropout(mlggd_engine *e, int layer, const float *chunk_rows) {
     const float p = (layer == 0) ? e->cfg.visible_omit : e->cfg.hid_omit;
     const size_t n = (size_t)e->lsp[layer] * e->Bp;
     float *rows = (layer == 0) ? const_cast<float *>(chunk_rows) : e->Y[layer];
-    const int ld = (layer == 0) ? e->K0 : e->lsp[layer];
+    const int ld = e->lsp[layer];
     hipLaunchKernelGGL(k_dropout, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, e->Yt[layer], rows,
                        e->ls[layer], e->lsp[layer], ld, e->B, e->Bp, p, (unsigned)e->cfg.random_seed,
                        e->step_counter * 16u + (unsigned)layer);
@@ -406,14 +433,14 @@ enum { GATHER_INPUT = 1, GATHER_HIDDEN = 2, GATHER_HIDDEN_EACH = 4 };  // data-p
 static int run_forward(mlggd_engine *e, const Bunch &bn, int frames, bool training, bool prestaged = false,
                        int gather_flags = 0) {
     if (prestaged) {
-        if (bn.first) e->in_bunch = in_bunch_other(e);
+        e->in_bunch = in_bunch_other(e);
     } else {
         CHK(run_transpose(e, bn, frames));
     }
     const float *in_rows = bunch_rows(e, bn);
     if (gather_flags & GATHER_INPUT) {  // the input rows can travel from the first microsecond of the step
         CHK(gather_begin(e));
-        CHK(gather_one(e, in_rows, e->Yall[0], (size_t)frames * e->K0));
+        CHK(gather_one(e, in_rows, e->Yall[0], (size_t)e->Bp * e->lsp[0]));
         CHK(gather_end(e));
     }
     const int b_tiles = e->Bp / 32;
@@ -473,19 +500,19 @@ static int launch_dw(mlggd_engine *e, int l, const float *in_rows, bool fused, f
     const int Kp = e->lsp[l - 1], Np = e->lsp[l];
     const int k_wg = (Kp + 64 * T - 1) / (64 * T), n_wg = (Np + 64 * T - 1) / (64 * T);
     const float *A = (l == 1) ? in_rows : e->Y[l - 1];
-    const int ldA = (l == 1) ? e->K0 : Kp;
+    const int ldA = Kp;
     const size_t lds = (size_t)2 * (64 * T) * (64 * T) * sizeof(float);
     if (fused) CHK(ensure_lds(e, k_dw<T, true>, lds));
     else CHK(ensure_lds(e, k_dw<T, false>, lds));
     if (fused)
-        hipLaunchKernelGGL((k_dw<T, true>), dim3(k_wg * n_wg), dim3(256), lds, st, A, ldA, e->dEdX[l], e->W[l],
-                           e->dW[l], (float *)nullptr, e->bias[l], e->dbias[l], (float *)nullptr, e->ls[l - 1], e->ls[l], Np,
-                           e->B, e->Bp, n_wg, nf, e->cfg.momentum, e->cfg.lrate, e->cfg.weightcost,
-                           stamps_for(e, KC_DW, l, k_wg * n_wg));
+        launch_timed(e, k_dw<T, true>, dim3(k_wg * n_wg), dim3(256), lds, st, A, ldA, (const float *)e->dEdX[l], e->W[l],
+                     e->dW[l], (float *)nullptr, e->bias[l], e->dbias[l], (float *)nullptr, e->ls[l - 1], e->ls[l], Np,
+                     e->B, e->Bp, n_wg, nf, e->cfg.momentum, e->cfg.lrate, e->cfg.weightcost,
+                     stamps_for(e, KC_DW, l, k_wg * n_wg));
     else
-        hipLaunchKernelGGL((k_dw<T, false>), dim3(k_wg * n_wg), dim3(256), lds, st, A, ldA, e->dEdX[l], e->W[l],
-                           e->dW[l], e->G[l], e->bias[l], e->dbias[l], e->gb[l], e->ls[l - 1], e->ls[l], Np, e->B, e->Bp, n_wg,
-                           nf, e->cfg.momentum, e->cfg.lrate, e->cfg.weightcost, (long long *)nullptr);
+        launch_timed(e, k_dw<T, false>, dim3(k_wg * n_wg), dim3(256), lds, st, A, ldA, (const float *)e->dEdX[l], e->W[l],
+                     e->dW[l], e->G[l], e->bias[l], e->dbias[l], e->gb[l], e->ls[l - 1], e->ls[l], Np, e->B, e->Bp, n_wg,
+                     nf, e->cfg.momentum, e->cfg.lrate, e->cfg.weightcost, (long long *)nullptr);
     return launch_check("k_dw");
 }
 
@@ -514,12 +541,18 @@ static int launch_dwp_t(mlggd_engine *e, const DwpJobs &J, bool fused, hipStream
     const size_t lds = dwp_lds_floats() * sizeof(float);
     const int grid = dwp_grid(e, J.total);
     long long *stamps = stamps_for(e, KC_DW, stamp_layer, grid);
-    if (fused) {
+    bool bias_only = false;  // only the sharded data-parallel job tables hold bias-only tiles
+    for (int j = 0; j < J.njobs; j++) bias_only = bias_only || J.job[j].wd_off != 0;
+    if (bias_only) {
+        if (!fused) return fail(MLGGD_ERR_STATE, "bias-only tiles exist on the fused path only");
+        CHK(ensure_lds(e, k_dwp<H, true, true>, lds));
+        launch_timed(e, k_dwp<H, true, true>, dim3(grid), dim3(256), lds, st, J, stamps);
+    } else if (fused) {
         CHK(ensure_lds(e, k_dwp<H, true>, lds));
-        hipLaunchKernelGGL((k_dwp<H, true>), dim3(grid), dim3(256), lds, st, J, stamps);
+        launch_timed(e, k_dwp<H, true>, dim3(grid), dim3(256), lds, st, J, stamps);
     } else {
         CHK(ensure_lds(e, k_dwp<H, false>, lds));
-        hipLaunchKernelGGL((k_dwp<H, false>), dim3(grid), dim3(256), lds, st, J, stamps);
+        launch_timed(e, k_dwp<H, false>, dim3(grid), dim3(256), lds, st, J, stamps);
     }
     return launch_check("k_dwp");
 }
@@ -555,7 +588,7 @@ static bool gather_usable(const mlggd_engine *e, int world) {
 }
 static int gather_alloc(mlggd_engine *e) {
     const size_t rows = (size_t)e->world * e->Bp;
-    CHK(dev_alloc(e, &e->Yall[0], rows * e->K0));
+    CHK(dev_alloc(e, &e->Yall[0], rows * e->lsp[0]));
     for (int l = 1; l < e->L; l++) {
         if (l != e->L - 1) CHK(dev_alloc(e, &e->Yall[l], rows * e->lsp[l]));
         CHK(dev_alloc(e, &e->dEdXall[l], rows * e->lsp[l]));
@@ -804,7 +837,7 @@ static int fake_world_prepass(mlggd_engine *e, int sample0, float nf, float inv_
                 HIPCHK(hipMemcpyAsync(dst + (size_t)r * count, src, count * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
                 return MLGGD_OK;
             };
-            CHK(put(in_rows, e->Yall[0], (size_t)B * e->K0));
+            CHK(put(in_rows, e->Yall[0], (size_t)Bp * e->lsp[0]));
             for (int l = 1; l < L; l++) {
                 if (l != L - 1) CHK(put(e->Y[l], e->Yall[l], (size_t)Bp * e->lsp[l]));
                 CHK(put(e->dEdX[l], e->dEdXall[l], (size_t)Bp * e->lsp[l]));
@@ -1842,29 +1875,28 @@ int mlggd_debug_stamp_read(mlggd_handle e, long long *out, int cap_blocks, int *
 
 // Cost of one HIP-event bracket on the engine's stream, calibrated in-process: a kernel
 // bracketed once measures overhead + t, bracketed twice back to back overhead + 2t, so
-// overhead = 2*T1 - T2.  Uses the (idempotent) input-staging kernel on the resident chunk.
+// overhead = 2*T1 - T2.  Uses an empty kernel (a kernel that writes memory would make the second of two
+// back-to-back launches wait for the first one's dirty lines and skew T2).
 int mlggd_profile_overhead(mlggd_handle e, float *usec) {
     if (!e || !usec) return fail(MLGGD_ERR_ARG, "NULL argument");
-    if (e->chunk_frames < 1) return fail(MLGGD_ERR_STATE, "no resident chunk");
     HIPCHK(hipSetDevice(e->device));
-    const int reps = 24;
+    const int reps = 40;
     std::vector<hipEvent_t> ev(4 * reps);
     for (auto &x : ev) HIPCHK(hipEventCreate(&x));
-    const Bunch bn = bunch_at(e, 0);
-    const int frames = e->chunk_frames < e->B ? e->chunk_frames : e->B;
-    const int saved = e->prof_class;
-    e->prof_class = -1;
+    auto nop = [&]() -> int {
+        hipLaunchKernelGGL(k_nop, dim3(256), dim3(256), 0, e->stream);
+        return launch_check("k_nop");
+    };
     for (int r = 0; r < reps; r++) {
         HIPCHK(hipEventRecord(ev[4 * r], e->stream));
-        CHK(run_transpose(e, bn, frames));
+        CHK(nop());
         HIPCHK(hipEventRecord(ev[4 * r + 1], e->stream));
         HIPCHK(hipEventRecord(ev[4 * r + 2], e->stream));
-        CHK(run_transpose(e, bn, frames));
-        CHK(run_transpose(e, bn, frames));
+        CHK(nop());
+        CHK(nop());
         HIPCHK(hipEventRecord(ev[4 * r + 3], e->stream));
     }
     HIPCHK(hipStreamSynchronize(e->stream));
-    e->prof_class = saved;
     double t1 = 0, t2 = 0;
     for (int r = 4; r < reps; r++) {  // first reps warm up
         float a = 0, b = 0;

@@ -290,12 +290,19 @@ __device__ __forceinline__ void dx_body(const DxArgs &A, const int bid, float *s
     const int voW = ((k0 + wr0) * Np + 4 * wc4) * 4;
     const int r8 = lane >> 3, c4 = lane & 7;      // dEdXt staging: 8 lanes per row, 8 rows per instruction
     const int voD = (r8 * Bp + b0 + 4 * c4) * 4;
+    // Columns 32..63 of a W-piece row are stored with their dword PAIRS swapped (n -> n ^ 2): the two 8-byte stores
+    // of a lane's float4 then go to dwords {4c, 4c+1} / {4c+2, 4c+3} for c < 8 and to {4c+2, 4c+3} / {4c, 4c+1} for
+    // c >= 8, so the 16 lanes of one ds_write_b64 group (one row) cover all 32 banks once.  Written in natural
+    // order, lanes c and c+8 hit the same bank pair: the 2-way conflict SQ_LDS_BANK_CONFLICT showed for this
+    // kernel in round 1 (192 cycles per wave, 20 % of its LDS cycles).  The reads below undo the swap.
+    const int wsw = (wc4 >= 8) ? 2 : 0;
     float *wdst = wb + wr0 * DX_LDW + 4 * wc4;
     // rows of the dEdXt piece are stored with bits 0 and 1 of the row number swapped: the two half-waves of a
     // fragment read (rows 4j and 4j+2, or 4j+1 and 4j+3) then sit 32 words apart, in different bank halves,
     // and the two values a lane needs per MFMA pair sit 64 words apart: one ds_read2st64_b32 (-0.8 us)
     float *ddst = db + ((r8 & ~3) | ((r8 & 1) << 1) | ((r8 >> 1) & 1)) * 32 + 4 * c4;
-    const float *ard = wb + i * DX_LDW + 2 * h;
+    const float *ard = wb + i * DX_LDW + 2 * h;            // n < 32: natural order
+    const float *ard_hi = wb + i * DX_LDW + 2 * (1 - h);   // n >= 32: dword pairs swapped (see wsw)
     const float *brd = db + h * 32 + i;
 
     f32x16 acc;
@@ -317,8 +324,8 @@ __device__ __forceinline__ void dx_body(const DxArgs &A, const int bid, float *s
     {                                                                                      \
         _Pragma("unroll") for (int it = 0; it < 8; it++) {                                 \
             float *dst = wdst + (4 * it) * DX_LDW;                                         \
-            *reinterpret_cast<float2 *>(dst) = make_float2(WR[it].x, WR[it].y);            \
-            *reinterpret_cast<float2 *>(dst + 2) = make_float2(WR[it].z, WR[it].w);        \
+            *reinterpret_cast<float2 *>(dst + wsw) = make_float2(WR[it].x, WR[it].y);      \
+            *reinterpret_cast<float2 *>(dst + (2 - wsw)) = make_float2(WR[it].z, WR[it].w); \
             *reinterpret_cast<float4 *>(ddst + it * 256) = DR[it];                         \
         }                                                                                  \
         __builtin_amdgcn_wave_barrier();                                                   \
@@ -327,7 +334,7 @@ __device__ __forceinline__ void dx_body(const DxArgs &A, const int bid, float *s
     {                                                                                      \
         _Pragma("unroll") for (int j = 0; j < 16; j++) {                                   \
             if (j < (CNT)) {                                                               \
-                const float2 av = *reinterpret_cast<const float2 *>(ard + 4 * j);          \
+                const float2 av = *reinterpret_cast<const float2 *>((j < 8 ? ard : ard_hi) + 4 * j); \
                 acc = mfma32(av.x, brd[(4 * j) * 32], acc);                                \
                 acc = mfma32(av.y, brd[(4 * j + 2) * 32], acc);                            \
             }                                                                              \
@@ -662,7 +669,10 @@ __device__ __forceinline__ DwpTile dwp_locate(const DwpJobs &J, const int t, con
 }
 
 // bid / nblocks: this workgroup's index and the number of workgroups walking the tiles
-template <int H, bool FUSED, bool interleave = true>
+// BO: the job table may hold bias-only tiles (sharded data parallel), whose MFMA loop is skipped.  That skip is a
+// branch around the MFMAs, i.e. a basic-block boundary between them and the unit's loads -- and the instruction
+// interleave below only works inside ONE block -- so the single-GPU / replicated instances are built without it.
+template <int H, bool FUSED, bool BO = false, bool interleave = true>
 __device__ __forceinline__ void dwp_body(const DwpJobs &J, const int bid, const int nblocks, float *lds,
                                          long long *stamps) {
     stamp_clk(stamps, 0, bid);  // diagnostic (nullptr in every normal launch): wall + shader clock at start / end
@@ -733,8 +743,13 @@ __device__ __forceinline__ void dwp_body(const DwpJobs &J, const int bid, const 
     {                                                                                           \
         const float *ap = lds + (BUF)*8192 + h5 * 64 + 32 * wm + i;                             \
         const float *bp = lds + (BUF)*8192 + 4096 + h5 * 64 + 32 * wn + i;                      \
+        float fa[32], fb[32]; /* static indices only: registers; DWP_INTERLEAVE decides how far ahead they are read */ \
+        _Pragma("unroll") for (int p = 0; p < 32; p++) {                                        \
+            fa[p] = ap[p * 128];                                                                \
+            fb[p] = bp[p * 128];                                                                \
+        }                                                                                       \
         /* bias-only tiles (szW == 0) have nothing to multiply */                               \
-        if (tc.szW != 0) { _Pragma("unroll") for (int p = 0; p < 32; p++) acc = mfma32(ap[p * 128], bp[p * 128], acc); } \
+        if (!BO || tc.szW != 0) { _Pragma("unroll") for (int p = 0; p < 32; p++) acc = mfma32(fa[p], fb[p], acc); } \
     }
 #define DWP_BIAS(BUF, HH)                                                                       \
     {                                                                                           \
@@ -770,14 +785,21 @@ __device__ __forceinline__ void dwp_body(const DwpJobs &J, const int bid, const 
                 }                                                                               \
             }                                                                                   \
         }                                                                                       \
-        __syncthreads(); /* every wave is done reading BUF: reuse it as transposition scratch */ \
-        float *Tw = lds + (BUF)*8192 + wave * 1024;                                             \
-        _Pragma("unroll") for (int r = 0; r < 16; r++) Tw[acc_row(r, lane) * 32 + i] = acc[r];  \
+        /* Transposition scratch without a workgroup barrier: the OTHER buffer is free (every wave finished        \
+           reading it before the barrier that ended the previous unit) and is about to be overwritten with the   \
+           next unit's operands; wave w's 32x32 scratch tile lives exactly in the 16 A-rows of that buffer that   \
+           wave w itself overwrites there (rows 4w..4w+3 of every group of 16: scratch word s -> row 4w + (s>>6&3) \
+           + 16*(s>>8), column s&63), so no other wave's data is touched and one wave's LDS operations are ordered */ \
+        float *Tw = lds + ((BUF) ^ 1) * 8192 + wave * 256;                                      \
+        _Pragma("unroll") for (int r = 0; r < 16; r++) {                                        \
+            const int kl = acc_row(r, lane);                                                    \
+            Tw[(kl >> 3) * 1024 + ((kl >> 1) & 3) * 64 + (kl & 1) * 32 + i] = acc[r];           \
+        }                                                                                       \
         __builtin_amdgcn_wave_barrier();                                                        \
         const rsrc_t rWc = make_rsrc(tc.Wt, FUSED ? tc.szW : 0), rDc = make_rsrc(tc.delta, FUSED ? tc.szW : 0); \
         const rsrc_t rGc = make_rsrc(tc.G, FUSED ? 0 : tc.szW);                                 \
         _Pragma("unroll") for (int it = 0; it < 4; it++) {                                      \
-            const float4 g = *reinterpret_cast<const float4 *>(Tw + (er + 8 * it) * 32 + 4 * ec); \
+            const float4 g = *reinterpret_cast<const float4 *>(Tw + it * 1024 + (er >> 1) * 64 + (er & 1) * 32 + 4 * ec); \
             const int off = DWP_OFF(tc, it);                                                    \
             if (FUSED) {                                                                        \
                 const float4 w = PW[it];                                                        \
@@ -801,17 +823,24 @@ __device__ __forceinline__ void dwp_body(const DwpJobs &J, const int bid, const 
         if (nf_pow2) DWP_UPDATE(BUF, PW, PD, DWP_DIV_POW2)                                      \
         else DWP_UPDATE(BUF, PW, PD, DWP_DIV_EXACT)                                             \
     }
-    // Issue order inside a unit: the 8 + PPU vector loads are spread between the MFMAs (one load per
-    // two MFMAs) instead of ahead of them -- after a barrier all waves of the CU issue their loads at
-    // once and each waited ~0.7 us in the memory pipeline's queue before its first MFMA.
+    // Issue order inside a unit (one basic block: the unit's vector loads, its 32 LDS fragment-read pairs and its
+    // 32 MFMAs).  The fragments of two MFMA pairs are read ahead, then every group is {2 MFMAs, the fragment reads of
+    // the pair after next, one vector load}: an MFMA never waits for an LDS read issued just before it, and the
+    // 8 + PPU vector loads are spread between the MFMAs instead of ahead of them -- after a barrier all waves of the
+    // CU issue their loads at once and each waited ~0.7 us in the memory pipeline's queue before its first MFMA
+    // (MFMA and memory work only overlap when interleaved in ONE wave's stream: profiles/r01_overlap_probe.txt).
 #define DWP_INTERLEAVE()                                                                        \
     {                                                                                           \
         if (interleave) {                                                                       \
-            _Pragma("unroll") for (int g = 0; g < 8 + (FUSED ? PPU : 0); g++) {                 \
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                              \
+            constexpr int NV = 8 + (FUSED ? PPU : 0);                                           \
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                  \
+            _Pragma("unroll") for (int g = 0; g < 14; g++) {                                    \
                 __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                              \
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                              \
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                              \
+                if (g + 14 < NV) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);             \
+                else if (g < NV) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);             \
             }                                                                                   \
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                  \
         }                                                                                       \
     }
     // one tile whose first unit sits in LDS buffer BASE: PWC/PDC = this tile's W/delta registers,
@@ -881,9 +910,9 @@ template <int NW>
 __global__ __launch_bounds__(64 * NW) void k_dx(DxArgs A, long long *stamps) {
     dx_body<NW>(A, (int)blockIdx.x, g_dyn_lds, stamps);
 }
-template <int H, bool FUSED>
+template <int H, bool FUSED, bool BO = false>
 __global__ __launch_bounds__(256) void k_dwp(DwpJobs J, long long *stamps) {
-    dwp_body<H, FUSED>(J, (int)blockIdx.x, (int)gridDim.x, g_dyn_lds, stamps);
+    dwp_body<H, FUSED, BO>(J, (int)blockIdx.x, (int)gridDim.x, g_dyn_lds, stamps);
 }
 // Elementwise update from an (all-reduced) gradient, data-parallel path.  Pad entries have
 // G = delta = W = 0 and stay 0.  kernUpdatedelta + kernAccSum, DevFunc.cu:490-507,427-443.
@@ -907,6 +936,9 @@ __global__ __launch_bounds__(256) void k_apply_update(float *__restrict__ Wt, fl
         reinterpret_cast<float4 *>(Wt)[idx] = w;
     }
 }
+
+// does nothing: the kernel mlggd_profile_overhead brackets to calibrate what a HIP-event bracket costs by itself
+__global__ __launch_bounds__(256) void k_nop() {}
 
 // dst = a + b elementwise (a == nullptr: dst = b).  Only the one-GPU emulation of the data-parallel
 // exchange uses it (mlggd_debug_fake_world: the sum over emulated ranks that a collective would form).
@@ -954,12 +986,15 @@ __global__ __launch_bounds__(256) void k_bias_apply(BiasJobs jobs, float nf, flo
 //   first == nullptr : the caller's expanded chunk, row b at in + b*ld           (BP_GPU::train)
 //   first != nullptr : the raw frame stream; row b is the contiguous slice that starts at frame
 //                      first[b], i.e. in + first[b]*fdim  (the window IS consecutive frames, so
-//                      nothing has to be expanded on the host).  The gathered rows are also
-//                      written row-major to rows_out[b][K] for the layer-1 dW operand.
+//                      nothing has to be expanded on the host).
+// Either way the rows are also written row-major to rows_out[b][Kp] (row stride Kp = ceil32(K), zeros in
+// the pad columns and pad rows): the layer-1 operand of the dW kernel.  The caller's rows have a stride of K
+// floats -- 2827 is odd, so three rows out of four start off a 16-byte boundary and every 16-byte load of
+// the dW kernel from them splits -- the copy costs 1.4 MB of writes in a kernel that touches every element anyway.
 // ---------------------------------------------------------------------------------------
 struct StageArgs {
     const float *in;
-    int ld, B, K;
+    int ld, B, K, Kp;
     float *inT;
     int Bp, b_tiles;
     const int *first;
@@ -982,8 +1017,8 @@ __device__ __forceinline__ void transpose_in_body(const StageArgs &A, const int 
         if (b < B && k < K) {
             const size_t base = first ? (size_t)first[b] * fdim : (size_t)b * ld;
             v = in[base + k];
-            if (rows_out) rows_out[(size_t)b * K + k] = v;
         }
+        if (rows_out) rows_out[(size_t)b * A.Kp + k] = v;  // b < Bp, k < Kp: the grid's tiles cover exactly that
         t[ty + 8 * q][tx] = v;
     }
     __syncthreads();
