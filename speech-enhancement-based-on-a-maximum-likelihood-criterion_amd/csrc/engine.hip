@@ -191,6 +191,13 @@ struct mlggd_engine {
     long long *stamp_buf = nullptr;
     size_t stamp_cap = 0;
 
+    struct DwpTable {  // one cached launch plan of the persistent dW kernel (dwp_table)
+        DwpJobs key;
+        bool fused;
+        int grid;
+        DwpDesc *dev;
+    };
+    std::vector<DwpTable> dwp_tables;
     std::vector<void *> allocs;
     std::vector<const void *> lds_attr_done;  // kernels whose dynamic-LDS limit has been raised on this device
 };
@@ -536,23 +543,113 @@ static DwpJobs dwp_jobs(mlggd_engine *e, int lhi, int llo, const float *in_rows,
     J.total = end;
     return J;
 }
+// The per-tile records the persistent dW kernel walks (kernels.hip.h DwpDesc), built once per launch plan and
+// kept on the device: the plan is the job list (which layers / row blocks / operands) and the grid.  A training
+// run uses two plans (the layer-1 operand alternates between the two staged-row buffers), a data-parallel run
+// a few more.  Hyper-parameters are not part of the plan: they travel in DwpConst with every launch.
+static int dwp_table(mlggd_engine *e, const DwpJobs &J, bool fused, int grid, const DwpDesc **out) {
+    DwpJobs key = J;
+    for (int j = 0; j < DWP_MAXJOBS; j++) {
+        DwpArgs &a = key.job[j];
+        if (j >= J.njobs) memset(&a, 0, sizeof(a));
+        a.nf = a.mom = a.lr = a.wc = 0.0f;
+        a.B = 0;
+    }
+    for (const auto &t : e->dwp_tables)
+        if (t.fused == fused && t.grid == grid && memcmp(&t.key, &key, sizeof(key)) == 0) {
+            *out = t.dev;
+            return MLGGD_OK;
+        }
+    std::vector<DwpDesc> recs((size_t)J.total + 2 * (size_t)grid);
+    size_t n = 0;
+    for (int j = 0; j < J.njobs; j++) {
+        const DwpArgs &a = J.job[j];
+        for (int tl = 0; tl < a.ntiles; tl++, n++) {
+            const int kt = a.k_first + tl / a.n_wg, nt = tl % a.n_wg;
+            const int k0 = kt * 64, n0 = nt * 64;
+            DwpDesc &d = recs[n];
+            d.A = a.Yrow + k0;
+            d.Bm = a.dEdX + n0;
+            const size_t base = (size_t)k0 * a.Np + n0;
+            int rows = a.K - k0;
+            rows = rows < 0 ? 0 : rows > 64 ? 64 : rows;
+            if (a.wd_off) {  // bias-only tile: W / delta are neither read nor written
+                rows = 0;
+                d.W = a.Wt;
+                d.D = a.delta;
+                d.szW = 0;
+            } else {
+                d.W = (fused ? a.Wt : a.G) + base;
+                d.D = fused ? a.delta + base : nullptr;
+                d.szW = (unsigned)(((size_t)a.Kp * a.Np - base) * sizeof(float));
+            }
+            const int colsw = a.Np - n0 < 64 ? a.Np - n0 : 64;
+            int nbias = (a.do_bias && kt == 0) ? a.N - n0 : 0;
+            nbias = nbias < 0 ? 0 : nbias > 64 ? 64 : nbias;
+            d.bias = (fused ? a.bias : a.gb) + n0;
+            d.dbias = fused ? a.dbias + n0 : nullptr;
+            d.ldA = a.ldA;
+            d.Np = a.Np;
+            d.packed = (unsigned)rows | ((unsigned)colsw << 8) | ((unsigned)nbias << 16) | (1u << 24);
+        }
+    }
+    if (n != (size_t)J.total) return fail(MLGGD_ERR_STATE, "dW tile table: %zu records for %d tiles", n, J.total);
+    for (; n < recs.size(); n++) {  // "no such tile": empty descriptors -- loads return zeros, stores are dropped
+        DwpDesc &d = recs[n];
+        d = recs[0];
+        d.packed = 0;
+        d.szW = 0;
+    }
+    mlggd_engine::DwpTable t;
+    t.key = key;
+    t.fused = fused;
+    t.grid = grid;
+    t.dev = nullptr;
+    HIPCHK(hipMalloc((void **)&t.dev, recs.size() * sizeof(DwpDesc)));
+    // pageable source, synchronous copy: complete when the call returns, so the launch that follows sees it
+    HIPCHK(hipMemcpy(t.dev, recs.data(), recs.size() * sizeof(DwpDesc), hipMemcpyHostToDevice));
+    e->dwp_tables.push_back(t);
+    *out = t.dev;
+    return MLGGD_OK;
+}
+
 template <int H>
 static int launch_dwp_t(mlggd_engine *e, const DwpJobs &J, bool fused, hipStream_t st, int stamp_layer) {
     const size_t lds = dwp_lds_floats() * sizeof(float);
     const int grid = dwp_grid(e, J.total);
+    if (J.total < 1) return MLGGD_OK;
+    const DwpDesc *table = nullptr;
+    CHK(dwp_table(e, J, fused, grid, &table));
+    DwpConst C;
+    C.B = J.job[0].B;
+    C.nf = J.job[0].nf;
+    C.mom = J.job[0].mom;
+    C.lr = J.job[0].lr;
+    C.wc = J.job[0].wc;
+    if constexpr (H == 2 || H == 8) {
+        if (e->stamp_class == KC_DW && e->stamp_layer == -1 && e->stamp_buf && fused) {
+            // diagnostic: the twin kernel with per-phase cycle sums (rows grid .. 2*grid-1 of the stamp buffer)
+            long long *sp = stamps_for(e, KC_DW, -1, 2 * grid);
+            if (sp) {
+                CHK(ensure_lds(e, k_dwp_phases<H>, lds));
+                hipLaunchKernelGGL((k_dwp_phases<H>), dim3(grid), dim3(256), lds, st, table, J.total, C, sp);
+                return launch_check("k_dwp_phases");
+            }
+        }
+    }
     long long *stamps = stamps_for(e, KC_DW, stamp_layer, grid);
     bool bias_only = false;  // only the sharded data-parallel job tables hold bias-only tiles
     for (int j = 0; j < J.njobs; j++) bias_only = bias_only || J.job[j].wd_off != 0;
     if (bias_only) {
         if (!fused) return fail(MLGGD_ERR_STATE, "bias-only tiles exist on the fused path only");
         CHK(ensure_lds(e, k_dwp<H, true, true>, lds));
-        launch_timed(e, k_dwp<H, true, true>, dim3(grid), dim3(256), lds, st, J, stamps);
+        launch_timed(e, k_dwp<H, true, true>, dim3(grid), dim3(256), lds, st, table, J.total, C, stamps);
     } else if (fused) {
         CHK(ensure_lds(e, k_dwp<H, true>, lds));
-        launch_timed(e, k_dwp<H, true>, dim3(grid), dim3(256), lds, st, J, stamps);
+        launch_timed(e, k_dwp<H, true>, dim3(grid), dim3(256), lds, st, table, J.total, C, stamps);
     } else {
         CHK(ensure_lds(e, k_dwp<H, false>, lds));
-        launch_timed(e, k_dwp<H, false>, dim3(grid), dim3(256), lds, st, J, stamps);
+        launch_timed(e, k_dwp<H, false>, dim3(grid), dim3(256), lds, st, table, J.total, C, stamps);
     }
     return launch_check("k_dwp");
 }
@@ -1135,6 +1232,7 @@ int mlggd_destroy(mlggd_handle e) {
     if (e->chunk_targ) hipFree(e->chunk_targ);
     if (e->chunk_out) hipFree(e->chunk_out);
     if (e->cv_partial) hipFree(e->cv_partial);
+    for (auto &t : e->dwp_tables) hipFree(t.dev);
     if (e->copy_stream) hipStreamSynchronize(e->copy_stream);
     for (auto &r : e->raw) {
         if (r.feat) hipFree(r.feat);

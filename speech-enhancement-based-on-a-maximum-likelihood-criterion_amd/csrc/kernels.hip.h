@@ -637,47 +637,61 @@ struct DwpJobs {
 };
 constexpr int dwp_lds_floats() { return 2 * 8192; }
 
-// everything the pipeline needs to know about one 64x64 tile (wave-uniform -> SGPRs)
-struct DwpTile {
-    const float *Yrow, *dEdX;
-    float *Wt, *delta, *G, *bias, *dbias, *gb;
-    int ldA, K, N, Np, k0, n0;
-    unsigned szA, szB, szW;  // descriptor sizes in bytes; 0 = "no such tile": loads give 0, stores are dropped
+// Everything the pipeline needs to know about one 64x64 tile, as ONE 64-byte record of a table the host builds
+// once per launch plan (engine.hip dwp_table): the walk t -> (layer, k0, n0, pointers) used to be done by every wave
+// at the start of every tile -- a scan of the job table in kernel-argument memory, an integer division and two
+// more dependent scalar loads, ~1.5k cycles during which the wave issued no MFMA (tools/dwp_phases.py, round 2).
+// Now it is one 64-byte record fetched a whole tile ahead: ONE vector load per wave (lanes 0..3 take a quarter
+// each), turned into scalars with v_readlane when the tile becomes current.  (A scalar load would be the obvious
+// instruction, but SMEM shares the lgkmcnt counter with LDS and returns out of order, so every LDS fragment read
+// issued while it is in flight has to be waited for with lgkmcnt(0) -- the record's memory latency then lands in
+// front of the tile's first MFMA.)  All pointers are already offset to the tile.
+struct DwpDesc {
+    const float *A;   // Y_{l-1} + k0            (rows = frames, row stride ldA)
+    const float *Bm;  // dEdX_l + n0             (row stride Np)
+    float *W;         // FUSED: W_l + k0*Np + n0;      otherwise G_l + k0*Np + n0
+    float *D;         // FUSED: delta_l + k0*Np + n0
+    float *bias;      // tiles of weight-row block 0 that own the bias update: FUSED bias_l + n0, otherwise gb_l + n0
+    float *dbias;     // FUSED: dbias_l + n0
+    int ldA, Np;
+    unsigned packed;  // rows | colsw << 8 | nbias << 16 | valid << 24: weight rows / columns of the tile that exist
+                      // (0 rows: bias-only tile, W / delta are not touched), bias columns this tile updates (0: none)
+    unsigned szW;     // bytes from W (and D) to the end of the layer's matrix: the range the stores may touch
 };
-__device__ __forceinline__ DwpTile dwp_locate(const DwpJobs &J, const int t, const int Bp) {
-    DwpTile T;
-    int j = 0, first = 0;
-#pragma unroll 1
-    for (int q = 0; q + 1 < J.njobs; q++)
-        if (t >= J.tile_end[q]) {
-            j = q + 1;
-            first = J.tile_end[q];
-        }
-    const DwpArgs &A = J.job[j];
-    const bool valid = t < J.total;
-    const int tl = valid ? t - first : 0;
-    T.Yrow = A.Yrow; T.dEdX = A.dEdX; T.Wt = A.Wt; T.delta = A.delta; T.G = A.G;
-    T.bias = A.bias; T.dbias = A.dbias; T.gb = A.gb;
-    T.ldA = A.ldA; T.K = A.K; T.Np = A.Np;
-    T.N = A.do_bias ? A.N : 0;  // N only bounds the bias update
-    T.k0 = (A.k_first + tl / A.n_wg) * 64;
-    T.n0 = (tl % A.n_wg) * 64;
-    T.szA = valid ? (unsigned)Bp * A.ldA * 4u : 0u;
-    T.szB = valid ? (unsigned)Bp * A.Np * 4u : 0u;
-    T.szW = (valid && !A.wd_off) ? (unsigned)A.Kp * A.Np * 4u : 0u;
-    return T;
+static_assert(sizeof(DwpDesc) == 64, "four 16-byte quarters per record");
+struct DwpRaw {
+    unsigned w[16];
+};
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// the quarter this lane fetched (lanes 0..3 hold the whole record) -> wave-uniform record
+__device__ __forceinline__ DwpDesc dwp_decode(u32x4 v) {
+    DwpRaw r;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) r.w[4 * q + c] = (unsigned)__builtin_amdgcn_readlane((int)v[c], q);
+    return __builtin_bit_cast(DwpDesc, r);
 }
+struct DwpConst {
+    int B;  // frames of the (global) minibatch: the bias gradient sums rows 0..B-1
+    float nf, mom, lr, wc;
+};
 
-// bid / nblocks: this workgroup's index and the number of workgroups walking the tiles
-// BO: the job table may hold bias-only tiles (sharded data parallel), whose MFMA loop is skipped.  That skip is a
+// bid / nblocks: this workgroup's index and the number of workgroups walking the tiles; the table holds
+// total + 2*nblocks records (the tail ones invalid: their loads return zeros, their stores are dropped).
+// BO: the table may hold bias-only tiles (sharded data parallel), whose MFMA loop is skipped.  That skip is a
 // branch around the MFMAs, i.e. a basic-block boundary between them and the unit's loads -- and the instruction
 // interleave below only works inside ONE block -- so the single-GPU / replicated instances are built without it.
-template <int H, bool FUSED, bool BO = false, bool interleave = true>
-__device__ __forceinline__ void dwp_body(const DwpJobs &J, const int bid, const int nblocks, float *lds,
-                                         long long *stamps) {
+// PHASES: diagnostic build only (mlggd_debug_stamp_select("dw", -1)): wave 0 sums the shader-clock cycles it spends
+// in each phase of a tile over all its tiles and writes the five sums to row nblocks + bid of the stamp buffer:
+// [0] units 0..H-2: loads + MFMAs, [1] their operand hand-off (vmcnt wait, LDS write, barrier), [2] last unit's loads
+// + MFMAs, [3] epilogue (transposition, update, stores), [4] last hand-off.  The production instances carry none of it.
+template <int H, bool FUSED, bool BO = false, bool interleave = true, bool PHASES = false>
+__device__ __forceinline__ void dwp_body(const DwpDesc *__restrict__ table, const int total, const DwpConst C, const int bid,
+                                         const int nblocks, float *lds, long long *stamps) {
     stamp_clk(stamps, 0, bid);  // diagnostic (nullptr in every normal launch): wall + shader clock at start / end
-    const int B = J.job[0].B;
-    const float nf = J.job[0].nf, mom = J.job[0].mom, lr = J.job[0].lr, wc = J.job[0].wc;
+    const int B = C.B;
+    const float nf = C.nf, mom = C.mom, lr = C.lr, wc = C.wc;
     // G / n_frames: for a power-of-two minibatch x / 2^m == x * 2^-m bit for bit (also when the result is
     // subnormal: both are the correctly rounded value of the same real number), and the multiply saves the
     // ~10-instruction IEEE division sequence per weight (40 % of this kernel's VALU instructions)
@@ -690,7 +704,6 @@ __device__ __forceinline__ void dwp_body(const DwpJobs &J, const int bid, const 
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
     const int i = lane & 31, h5 = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
-    const int Bp = 64 * H;
 
     const int scol = tid & 15, srow = tid >> 4;  // staging: 16 float4 per 64-float row, 16 rows per pass
     const int ec = lane & 7, er = lane >> 3;     // epilogue: 8 float4 per 32-float wave-tile row
@@ -703,16 +716,25 @@ __device__ __forceinline__ void dwp_body(const DwpJobs &J, const int bid, const 
     float bsum = 0.0f;
 
     int t = bid;
-    if (t >= J.total) return;
-    DwpTile tc = dwp_locate(J, t, Bp);
+    if (t >= total) return;
+    // current tile, next tile, and the one after (its record is in flight during the whole current tile)
+    const rsrc_t rT = make_rsrc(table, ((size_t)total + 2 * (size_t)nblocks) * sizeof(DwpDesc));
+    const int voT = 16 * (lane & 3);
+#define DWP_FETCH(TI) __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rT, voT, (TI) * 64, 0))
+    DwpDesc tc = dwp_decode(DWP_FETCH(t)), tn = dwp_decode(DWP_FETCH(t + nblocks));
+    u32x4 tnn_raw;
 
+#define DWP_ROWS(T) ((int)((T).packed & 0xFFu))
+#define DWP_COLS(T) ((int)(((T).packed >> 8) & 0xFFu))
+#define DWP_NBIAS(T) ((int)(((T).packed >> 16) & 0xFFu))
+#define DWP_SZAB(T) ((((T).packed >> 24) & 1u) ? 0x7FFFFFFFu : 0u) /* operand reads never leave the allocation */
 #define DWP_LOAD_UNIT(T, HH)                                                                    \
     {                                                                                           \
-        const rsrc_t rA_ = make_rsrc(T.Yrow, T.szA), rB_ = make_rsrc(T.dEdX, T.szB);            \
+        const rsrc_t rA_ = make_rsrc(T.A, DWP_SZAB(T)), rB_ = make_rsrc(T.Bm, DWP_SZAB(T));     \
         _Pragma("unroll") for (int q = 0; q < 4; q++) {                                         \
             const int row = 64 * (HH) + srow + 16 * q;                                          \
-            ra[q] = bload4(rA_, (row * T.ldA + T.k0 + 4 * scol) * 4, 0);                        \
-            rb[q] = bload4(rB_, (row * T.Np + T.n0 + 4 * scol) * 4, 0);                         \
+            ra[q] = bload4(rA_, (row * T.ldA + 4 * scol) * 4, 0);                               \
+            rb[q] = bload4(rB_, (row * T.Np + 4 * scol) * 4, 0);                                \
         }                                                                                       \
     }
 #define DWP_WRITE_UNIT(BUF)                                                                     \
@@ -723,15 +745,15 @@ __device__ __forceinline__ void dwp_body(const DwpJobs &J, const int bid, const 
             *reinterpret_cast<float4 *>(bs + (srow + 16 * q) * 64 + 4 * scol) = rb[q];          \
         }                                                                                       \
     }
-    // voffset of this lane's float4 number IT of the wave tile of T; OOB for pad rows
+    // voffset of this lane's float4 number IT of the wave tile of T; OOB for rows / columns that do not exist
 #define DWP_OFF(T, IT)                                                                          \
-    (((T.k0 + 32 * wm + er + 8 * (IT)) < T.K && (T.n0 + 32 * wn + 4 * ec) < T.Np)               \
-         ? ((T.k0 + 32 * wm + er + 8 * (IT)) * T.Np + T.n0 + 32 * wn + 4 * ec) * 4              \
+    (((32 * wm + er + 8 * (IT)) < DWP_ROWS(T) && (32 * wn + 4 * ec) < DWP_COLS(T))               \
+         ? ((32 * wm + er + 8 * (IT)) * T.Np + 32 * wn + 4 * ec) * 4                            \
          : OOB)
 #define DWP_PREFETCH(PW, PD, T, HH)                                                             \
     {                                                                                           \
         if (FUSED) {                                                                            \
-            const rsrc_t rW_ = make_rsrc(T.Wt, T.szW), rD_ = make_rsrc(T.delta, T.szW);         \
+            const rsrc_t rW_ = make_rsrc(T.W, T.szW), rD_ = make_rsrc(T.D, T.szW);              \
             _Pragma("unroll") for (int jj = 0; jj < ((HH) % PEVERY == 0 ? PPU : 0); jj++) {     \
                 const int j = ((HH) / PEVERY) * PPU + jj;                                       \
                 if (j < 4) PW[j] = bload4(rW_, DWP_OFF(T, j), 0);                               \
@@ -748,12 +770,14 @@ __device__ __forceinline__ void dwp_body(const DwpJobs &J, const int bid, const 
             fa[p] = ap[p * 128];                                                                \
             fb[p] = bp[p * 128];                                                                \
         }                                                                                       \
-        /* bias-only tiles (szW == 0) have nothing to multiply */                               \
-        if (!BO || tc.szW != 0) { _Pragma("unroll") for (int p = 0; p < 32; p++) acc = mfma32(fa[p], fb[p], acc); } \
+        /* bias-only tiles (no weight rows) have nothing to multiply */                         \
+        if (!BO || DWP_ROWS(tc) != 0) { _Pragma("unroll") for (int p = 0; p < 32; p++) acc = mfma32(fa[p], fb[p], acc); } \
     }
+    // bias gradient of the tile's columns: frames summed sequentially in fp32 (kernAccSumrow order,
+    // DevFunc.cu:267-285 <- BP_GPU.cu:434); the dEdX unit is in LDS anyway
 #define DWP_BIAS(BUF, HH)                                                                       \
     {                                                                                           \
-        if (tc.k0 == 0 && tid < 64) {                                                           \
+        if (tid < DWP_NBIAS(tc)) {                                                              \
             const float *col = lds + (BUF)*8192 + 4096 + tid;                                   \
             int bend = B - 64 * (HH);                                                           \
             bend = bend < 64 ? bend : 64;                                                       \
@@ -772,17 +796,14 @@ __device__ __forceinline__ void dwp_body(const DwpJobs &J, const int bid, const 
     }
 #define DWP_UPDATE(BUF, PW, PD, DIVN)                                                               \
     {                                                                                           \
-        if (tc.k0 == 0 && tid < 64) {                                                           \
-            const int n = tc.n0 + tid;                                                          \
-            if (n < tc.N) {                                                                     \
-                if (FUSED) {                                                                    \
-                    const float bv = tc.bias[n];                                                \
-                    const float d = mom * tc.dbias[n] - lr * (DIVN(bsum) + 0.0f * bv);           \
-                    tc.dbias[n] = d;                                                            \
-                    tc.bias[n] = d + 1.0f * bv;                                                 \
-                } else {                                                                        \
-                    tc.gb[n] = bsum;                                                            \
-                }                                                                               \
+        if (tid < DWP_NBIAS(tc)) {                                                              \
+            if (FUSED) { /* kernUpdatedelta with weightcost 0 + kernAccSum, BP_GPU.cu:435,437 */ \
+                const float bv = tc.bias[tid];                                                  \
+                const float d = mom * tc.dbias[tid] - lr * (DIVN(bsum) + 0.0f * bv);            \
+                tc.dbias[tid] = d;                                                              \
+                tc.bias[tid] = d + 1.0f * bv;                                                   \
+            } else {                                                                            \
+                tc.bias[tid] = bsum;                                                            \
             }                                                                                   \
         }                                                                                       \
         /* Transposition scratch without a workgroup barrier: the OTHER buffer is free (every wave finished        \
@@ -796,12 +817,11 @@ __device__ __forceinline__ void dwp_body(const DwpJobs &J, const int bid, const 
             Tw[(kl >> 3) * 1024 + ((kl >> 1) & 3) * 64 + (kl & 1) * 32 + i] = acc[r];           \
         }                                                                                       \
         __builtin_amdgcn_wave_barrier();                                                        \
-        const rsrc_t rWc = make_rsrc(tc.Wt, FUSED ? tc.szW : 0), rDc = make_rsrc(tc.delta, FUSED ? tc.szW : 0); \
-        const rsrc_t rGc = make_rsrc(tc.G, FUSED ? 0 : tc.szW);                                 \
+        const rsrc_t rWc = make_rsrc(tc.W, tc.szW), rDc = make_rsrc(tc.D, FUSED ? tc.szW : 0);  \
         _Pragma("unroll") for (int it = 0; it < 4; it++) {                                      \
             const float4 g = *reinterpret_cast<const float4 *>(Tw + it * 1024 + (er >> 1) * 64 + (er & 1) * 32 + 4 * ec); \
             const int off = DWP_OFF(tc, it);                                                    \
-            if (FUSED) {                                                                        \
+            if (FUSED) { /* kernUpdatedelta (DevFunc.cu:502) then kernAccSum (DevFunc.cu:440) */ \
                 const float4 w = PW[it];                                                        \
                 float4 d = PD[it];                                                              \
                 d.x = mom * d.x - lr * (DIVN(g.x) + wc * w.x);                                   \
@@ -811,7 +831,7 @@ __device__ __forceinline__ void dwp_body(const DwpJobs &J, const int bid, const 
                 bstore4(d, rDc, off);                                                           \
                 bstore4(make_float4(d.x + 1.0f * w.x, d.y + 1.0f * w.y, d.z + 1.0f * w.z, d.w + 1.0f * w.w), rWc, off); \
             } else {                                                                            \
-                bstore4(g, rGc, off);                                                           \
+                bstore4(g, rWc, off);                                                           \
             }                                                                                   \
         }                                                                                       \
         _Pragma("unroll") for (int r = 0; r < 16; r++) acc[r] = 0.0f;                           \
@@ -843,12 +863,22 @@ __device__ __forceinline__ void dwp_body(const DwpJobs &J, const int bid, const 
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                  \
         }                                                                                       \
     }
+    long long ph_sum[5] = {0, 0, 0, 0, 0}, ph_last = 0;
+#define DWP_PHASE(K)                                                                            \
+    {                                                                                           \
+        if (PHASES) {                                                                           \
+            __builtin_amdgcn_sched_barrier(0);                                                  \
+            const long long now_ = (long long)__builtin_amdgcn_s_memtime();                     \
+            ph_sum[K] += now_ - ph_last;                                                        \
+            ph_last = now_;                                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                  \
+        }                                                                                       \
+    }
     // one tile whose first unit sits in LDS buffer BASE: PWC/PDC = this tile's W/delta registers,
     // PWN/PDN = the next tile's (an invalid next tile has empty descriptors: its loads cost nothing)
 #define DWP_TILE(PWC, PDC, PWN, PDN, BASE)                                                      \
     {                                                                                           \
-        const int tnext = t + nblocks;                                                          \
-        const DwpTile tn = dwp_locate(J, tnext, Bp);                                            \
+        tnn_raw = DWP_FETCH(t + 2 * nblocks); /* in flight until the end of this tile */        \
         _Pragma("unroll") for (int hh = 0; hh < H; hh++) {                                      \
             const int buf = ((BASE) + hh) & 1;                                                  \
             DWP_BIAS(buf, hh)                                                                   \
@@ -857,13 +887,19 @@ __device__ __forceinline__ void dwp_body(const DwpJobs &J, const int bid, const 
             DWP_PREFETCH(PWN, PDN, tn, hh)                                                      \
             DWP_MFMA(buf)                                                                       \
             DWP_INTERLEAVE()                                                                    \
-            if (hh == H - 1) DWP_EPILOGUE(buf, PWC, PDC)                                        \
+            DWP_PHASE(hh == H - 1 ? 2 : 0)                                                      \
+            if (hh == H - 1) {                                                                  \
+                DWP_EPILOGUE(buf, PWC, PDC)                                                     \
+                DWP_PHASE(3)                                                                    \
+            }                                                                                   \
             DWP_WRITE_UNIT(buf ^ 1)                                                             \
             __syncthreads();                                                                    \
+            DWP_PHASE(hh == H - 1 ? 4 : 1)                                                      \
         }                                                                                       \
-        if (tnext >= J.total) break;                                                            \
-        t = tnext;                                                                              \
+        t += nblocks;                                                                           \
+        if (t >= total) break;                                                                  \
         tc = tn;                                                                                \
+        tn = dwp_decode(tnn_raw);                                                               \
     }
 
     // prologue: first unit into buffer 0, this tile's W/delta into set 0
@@ -871,13 +907,20 @@ __device__ __forceinline__ void dwp_body(const DwpJobs &J, const int bid, const 
     _Pragma("unroll") for (int hh = 0; hh < H; hh++) DWP_PREFETCH(pw0, pd0, tc, hh)
     DWP_WRITE_UNIT(0)
     __syncthreads();
+    if (PHASES) ph_last = (long long)__builtin_amdgcn_s_memtime();
     // a tile of H units leaves its successor's first unit in buffer (BASE + H) & 1
     for (;;) {
         DWP_TILE(pw0, pd0, pw1, pd1, 0)
         DWP_TILE(pw1, pd1, pw0, pd0, H & 1)
     }
     stamp_clk(stamps, 2, bid);
-    if (stamps != nullptr && threadIdx.x == 0) stamps[(size_t)bid * 8 + 4] = (t - bid) / nblocks + 1;  // tiles walked
+    if (stamps != nullptr && threadIdx.x == 0) stamps[(size_t)bid * 8 + 4] = (t - bid) / nblocks;  // tiles walked
+    if (PHASES && stamps != nullptr && threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 5; k++) stamps[(size_t)(nblocks + bid) * 8 + k] = ph_sum[k];
+    }
+#undef DWP_PHASE
+#undef DWP_FETCH
 #undef DWP_LOAD_UNIT
 #undef DWP_WRITE_UNIT
 #undef DWP_OFF
@@ -890,6 +933,10 @@ __device__ __forceinline__ void dwp_body(const DwpJobs &J, const int bid, const 
 #undef DWP_DIV_POW2
 #undef DWP_TILE
 #undef DWP_INTERLEAVE
+#undef DWP_ROWS
+#undef DWP_COLS
+#undef DWP_NBIAS
+#undef DWP_SZAB
 }
 
 // ---------------------------------------------------------------------------------------
@@ -911,8 +958,13 @@ __global__ __launch_bounds__(64 * NW) void k_dx(DxArgs A, long long *stamps) {
     dx_body<NW>(A, (int)blockIdx.x, g_dyn_lds, stamps);
 }
 template <int H, bool FUSED, bool BO = false>
-__global__ __launch_bounds__(256) void k_dwp(DwpJobs J, long long *stamps) {
-    dwp_body<H, FUSED, BO>(J, (int)blockIdx.x, (int)gridDim.x, g_dyn_lds, stamps);
+__global__ __launch_bounds__(256) void k_dwp(const DwpDesc *__restrict__ table, int total, DwpConst C, long long *stamps) {
+    dwp_body<H, FUSED, BO>(table, total, C, (int)blockIdx.x, (int)gridDim.x, g_dyn_lds, stamps);
+}
+// diagnostic twin of k_dwp<H, true> with the per-phase cycle sums (never launched unless asked for)
+template <int H>
+__global__ __launch_bounds__(256) void k_dwp_phases(const DwpDesc *__restrict__ table, int total, DwpConst C, long long *stamps) {
+    dwp_body<H, true, false, true, true>(table, total, C, (int)blockIdx.x, (int)gridDim.x, g_dyn_lds, stamps);
 }
 // Elementwise update from an (all-reduced) gradient, data-parallel path.  Pad entries have
 // G = delta = W = 0 and stay 0.  kernUpdatedelta + kernAccSum, DevFunc.cu:490-507,427-443.
