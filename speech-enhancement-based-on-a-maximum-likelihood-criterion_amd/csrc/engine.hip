@@ -627,7 +627,7 @@ static int launch_dwp_t(mlggd_engine *e, const DwpJobs &J, bool fused, hipStream
     C.lr = J.job[0].lr;
     C.wc = J.job[0].wc;
     if constexpr (H == 2 || H == 8) {
-        if (e->stamp_class == KC_DW && e->stamp_layer == -1 && e->stamp_buf && fused) {
+        if (e->stamp_class == KC_DW && e->stamp_layer == -1 && e->stamp_buf && fused && C.nf == 128.0f) {
             // diagnostic: the twin kernel with per-phase cycle sums (rows grid .. 2*grid-1 of the stamp buffer)
             long long *sp = stamps_for(e, KC_DW, -1, 2 * grid);
             if (sp) {
@@ -638,19 +638,35 @@ static int launch_dwp_t(mlggd_engine *e, const DwpJobs &J, bool fused, hipStream
         }
     }
     long long *stamps = stamps_for(e, KC_DW, stamp_layer, grid);
-    bool bias_only = false;  // only the sharded data-parallel job tables hold bias-only tiles
-    for (int j = 0; j < J.njobs; j++) bias_only = bias_only || J.job[j].wd_off != 0;
-    if (bias_only) {
-        if (!fused) return fail(MLGGD_ERR_STATE, "bias-only tiles exist on the fused path only");
-        CHK(ensure_lds(e, k_dwp<H, true, true>, lds));
-        launch_timed(e, k_dwp<H, true, true>, dim3(grid), dim3(256), lds, st, table, J.total, C, stamps);
-    } else if (fused) {
-        CHK(ensure_lds(e, k_dwp<H, true>, lds));
-        launch_timed(e, k_dwp<H, true>, dim3(grid), dim3(256), lds, st, table, J.total, C, stamps);
-    } else {
-        CHK(ensure_lds(e, k_dwp<H, false>, lds));
-        launch_timed(e, k_dwp<H, false>, dim3(grid), dim3(256), lds, st, table, J.total, C, stamps);
+    if constexpr (H == 2) {
+        static const int abl = getenv("MLGGD_DWP_ABLATE") ? atoi(getenv("MLGGD_DWP_ABLATE")) : 0;
+        if (abl && fused) {  // timing-only diagnostics: results are wrong by construction
+#define DWP_ABL(A_)                                                                                       \
+    case A_:                                                                                              \
+        CHK(ensure_lds(e, k_dwp_ablate<H, A_>, lds));                                                     \
+        launch_timed(e, k_dwp_ablate<H, A_>, dim3(grid), dim3(256), lds, st, table, J.total, C, stamps);  \
+        return launch_check("k_dwp_ablate");
+            switch (abl) {
+                DWP_ABL(1) DWP_ABL(2) DWP_ABL(3) DWP_ABL(4) DWP_ABL(7) DWP_ABL(15) DWP_ABL(31) DWP_ABL(63) DWP_ABL(16) DWP_ABL(48)
+            default: return fail(MLGGD_ERR_ARG, "MLGGD_DWP_ABLATE=%d is not built", abl);
+            }
+#undef DWP_ABL
+        }
     }
+    // G / n is a multiply when n is a power of two (bit-identical, see kernels.hip.h POW2)
+    unsigned nfbits;
+    memcpy(&nfbits, &C.nf, sizeof(nfbits));
+    const bool pow2 = (nfbits & 0x007FFFFFu) == 0u && C.nf >= 1.0f;
+#define DWP_LAUNCH(FUSED_, POW2_)                                                                         \
+    {                                                                                                     \
+        CHK(ensure_lds(e, k_dwp<H, FUSED_, POW2_>, lds));                                                 \
+        launch_timed(e, k_dwp<H, FUSED_, POW2_>, dim3(grid), dim3(256), lds, st, table, J.total, C, stamps); \
+    }
+    if (fused && pow2) DWP_LAUNCH(true, true)
+    else if (fused) DWP_LAUNCH(true, false)
+    else if (pow2) DWP_LAUNCH(false, true)
+    else DWP_LAUNCH(false, false)
+#undef DWP_LAUNCH
     return launch_check("k_dwp");
 }
 static bool dwp_usable(const mlggd_engine *e) {

@@ -612,6 +612,9 @@ __global__ __launch_bounds__(256) void k_dw(const float *__restrict__ Yrow, int 
 // around any memory instruction the compiler's s_waitcnt vmcnt(N) before the LDS write
 // leaves exactly the younger prefetch loads in flight.
 // ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void bstore1(float v, rsrc_t r, int voff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, 0, 0);
+}
 __device__ __forceinline__ void bstore4(float4 v, rsrc_t r, int voff) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), r, voff, 0, 0);
 }
@@ -679,64 +682,79 @@ struct DwpConst {
 
 // bid / nblocks: this workgroup's index and the number of workgroups walking the tiles; the table holds
 // total + 2*nblocks records (the tail ones invalid: their loads return zeros, their stores are dropped).
-// BO: the table may hold bias-only tiles (sharded data parallel), whose MFMA loop is skipped.  That skip is a
-// branch around the MFMAs, i.e. a basic-block boundary between them and the unit's loads -- and the instruction
-// interleave below only works inside ONE block -- so the single-GPU / replicated instances are built without it.
-// PHASES: diagnostic build only (mlggd_debug_stamp_select("dw", -1)): wave 0 sums the shader-clock cycles it spends
-// in each phase of a tile over all its tiles and writes the five sums to row nblocks + bid of the stamp buffer:
-// [0] units 0..H-2: loads + MFMAs, [1] their operand hand-off (vmcnt wait, LDS write, barrier), [2] last unit's loads
-// + MFMAs, [3] epilogue (transposition, update, stores), [4] last hand-off.  The production instances carry none of it.
-template <int H, bool FUSED, bool BO = false, bool interleave = true, bool PHASES = false>
+//
+// Schedule (round 2; tools/dwp_phases.py showed a wave spending only half of a tile's cycles issuing MFMAs: the
+// rest was the tile walk, the epilogue and the operand hand-offs, during which its SIMD's matrix pipe had at
+// best the other workgroup's wave to run).  Now the wave's MFMA stream never stops for the epilogue:
+//   * the epilogue of tile t (accumulators -> LDS transposition -> momentum / weight-decay update -> 8 stores)
+//     is issued BETWEEN the MFMAs of the first unit of tile t+1, on a second accumulator set (the compiler renames
+//     the 16 accumulator registers; nothing is copied);
+//   * the W / delta tiles of tile t+1 are loaded during the LAST unit of tile t (between its MFMAs) and consumed a
+//     whole tile later, in the first unit of tile t+2: under load an HBM read takes longer than one unit lasts (a
+//     version that loaded them one unit ahead stalled ~2k cycles per tile on them), hence two register sets, used
+//     alternately: tile t's pending epilogue frees the set that the same tile's last unit refills;
+//   * every unit is ONE basic block whose issue order is written out group by group -- {2 MFMAs, the LDS fragment
+//     reads of the pair after next, one or two memory / epilogue operations} x 16 -- with a scheduling fence
+//     after each group: MFMA and memory work only overlap when interleaved in ONE wave's stream
+//     (profiles/r01_overlap_probe.txt), and an MFMA never waits for an LDS read issued just before it;
+//   * the transposition scratch of wave w lives in the 16 rows of the buffer being refilled that only wave w
+//     writes (rows 4w..4w+3 of every group of 16), used before the wave's own operand writes: no barrier;
+//   * the bias gradient / update of the tiles of weight-row block 0 stays outside the blocks (divergent, rare).
+// POW2: the minibatch size is a power of two, so G / n == G * (1/n) bit for bit (also when the result is subnormal:
+// both are the correctly rounded value of the same real number) and the ~10-instruction IEEE division per weight is
+// a multiply; chosen by the host (a run-time branch would split the blocks).
+// PHASES: diagnostic twin only (mlggd_debug_stamp_select("dw", -1)): wave 0 sums the shader-clock cycles of
+// [0] units 0..H-2 up to the last MFMA issue, [1] their hand-off (vmcnt wait, LDS write, barrier), [2] the last
+// unit, [3] unused, [4] the last hand-off, over all its tiles -> row nblocks + bid of the stamp buffer.
+// ABL: timing-only ablations of the diagnostic twins (wrong results by construction; MLGGD_DWP_ABLATE):
+// 1 no epilogue update / stores, 2 no W / delta loads, 4 no MFMAs, 8 no fragment reads and no MFMAs, 16 no operand
+// loads, 32 no operand LDS writes.
+template <int H, bool FUSED, bool POW2, bool PHASES = false, int ABL = 0>
 __device__ __forceinline__ void dwp_body(const DwpDesc *__restrict__ table, const int total, const DwpConst C, const int bid,
                                          const int nblocks, float *lds, long long *stamps) {
     stamp_clk(stamps, 0, bid);  // diagnostic (nullptr in every normal launch): wall + shader clock at start / end
     const int B = C.B;
     const float nf = C.nf, mom = C.mom, lr = C.lr, wc = C.wc;
-    // G / n_frames: for a power-of-two minibatch x / 2^m == x * 2^-m bit for bit (also when the result is
-    // subnormal: both are the correctly rounded value of the same real number), and the multiply saves the
-    // ~10-instruction IEEE division sequence per weight (40 % of this kernel's VALU instructions)
-    const bool nf_pow2 = (__float_as_uint(nf) & 0x007FFFFFu) == 0u && nf >= 1.0f;
     const float inv_nf = 1.0f / nf;
     constexpr int OOB = 0x7FFFFF00;  // byte offset beyond every descriptor: load -> 0, store dropped
-    // W/delta prefetch: 8 loads per tile and lane, spread over the tile's units -- PPU per unit for
-    // H <= 8, one every H/8 units beyond that
-    constexpr int PPU = H <= 8 ? 8 / H : 1, PEVERY = H <= 8 ? 1 : H / 8;
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
     const int i = lane & 31, h5 = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
-
     const int scol = tid & 15, srow = tid >> 4;  // staging: 16 float4 per 64-float row, 16 rows per pass
     const int ec = lane & 7, er = lane >> 3;     // epilogue: 8 float4 per 32-float wave-tile row
 
-    f32x16 acc;
+    f32x16 acc, accp;  // this tile's accumulators; the previous tile's, whose epilogue is pending
 #pragma unroll
-    for (int r = 0; r < 16; r++) acc[r] = 0.0f;
-    float4 ra[4], rb[4];
+    for (int r = 0; r < 16; r++) acc[r] = accp[r] = 0.0f;
+    float4 ra[4], rb[4];  // operands of the next unit on their way global -> LDS
+    // W / delta of tiles k (set k & 1): set 1 is consumed by the (empty) pending epilogue of the first tile
     float4 pw0[4], pd0[4], pw1[4], pd1[4];
-    float bsum = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 4; q++) pw1[q] = pd1[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float bsum = 0.0f, bsum_p = 0.0f;
 
     int t = bid;
     if (t >= total) return;
-    // current tile, next tile, and the one after (its record is in flight during the whole current tile)
     const rsrc_t rT = make_rsrc(table, ((size_t)total + 2 * (size_t)nblocks) * sizeof(DwpDesc));
     const int voT = 16 * (lane & 3);
 #define DWP_FETCH(TI) __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rT, voT, (TI) * 64, 0))
-    DwpDesc tc = dwp_decode(DWP_FETCH(t)), tn = dwp_decode(DWP_FETCH(t + nblocks));
+    // current tile, next tile (its record for the one after is in flight during the whole current tile), and the
+    // previous one, whose epilogue is pending: at first an invalid record (no rows: every store is dropped)
+    DwpDesc tc = dwp_decode(DWP_FETCH(t)), tn = dwp_decode(DWP_FETCH(t + nblocks)), tp = tc;
+    tp.packed = 0;
+    tp.szW = 0;
     u32x4 tnn_raw;
 
 #define DWP_ROWS(T) ((int)((T).packed & 0xFFu))
 #define DWP_COLS(T) ((int)(((T).packed >> 8) & 0xFFu))
 #define DWP_NBIAS(T) ((int)(((T).packed >> 16) & 0xFFu))
 #define DWP_SZAB(T) ((((T).packed >> 24) & 1u) ? 0x7FFFFFFFu : 0u) /* operand reads never leave the allocation */
-#define DWP_LOAD_UNIT(T, HH)                                                                    \
-    {                                                                                           \
-        const rsrc_t rA_ = make_rsrc(T.A, DWP_SZAB(T)), rB_ = make_rsrc(T.Bm, DWP_SZAB(T));     \
-        _Pragma("unroll") for (int q = 0; q < 4; q++) {                                         \
-            const int row = 64 * (HH) + srow + 16 * q;                                          \
-            ra[q] = bload4(rA_, (row * T.ldA + 4 * scol) * 4, 0);                               \
-            rb[q] = bload4(rB_, (row * T.Np + 4 * scol) * 4, 0);                                \
-        }                                                                                       \
-    }
+#define DWP_DIVN(x) (POW2 ? (x) * inv_nf : (x) / nf)
+    // voffset of this lane's float4 number IT of the wave tile of T; OOB for rows / columns that do not exist
+#define DWP_OFF(T, IT)                                                                          \
+    (((32 * wm + er + 8 * (IT)) < DWP_ROWS(T) && (32 * wn + 4 * ec) < DWP_COLS(T))               \
+         ? ((32 * wm + er + 8 * (IT)) * T.Np + 32 * wn + 4 * ec) * 4                            \
+         : OOB)
 #define DWP_WRITE_UNIT(BUF)                                                                     \
     {                                                                                           \
         float *as = lds + (BUF)*8192, *bs = as + 4096;                                          \
@@ -744,34 +762,6 @@ __device__ __forceinline__ void dwp_body(const DwpDesc *__restrict__ table, cons
             *reinterpret_cast<float4 *>(as + (srow + 16 * q) * 64 + 4 * scol) = ra[q];          \
             *reinterpret_cast<float4 *>(bs + (srow + 16 * q) * 64 + 4 * scol) = rb[q];          \
         }                                                                                       \
-    }
-    // voffset of this lane's float4 number IT of the wave tile of T; OOB for rows / columns that do not exist
-#define DWP_OFF(T, IT)                                                                          \
-    (((32 * wm + er + 8 * (IT)) < DWP_ROWS(T) && (32 * wn + 4 * ec) < DWP_COLS(T))               \
-         ? ((32 * wm + er + 8 * (IT)) * T.Np + 32 * wn + 4 * ec) * 4                            \
-         : OOB)
-#define DWP_PREFETCH(PW, PD, T, HH)                                                             \
-    {                                                                                           \
-        if (FUSED) {                                                                            \
-            const rsrc_t rW_ = make_rsrc(T.W, T.szW), rD_ = make_rsrc(T.D, T.szW);              \
-            _Pragma("unroll") for (int jj = 0; jj < ((HH) % PEVERY == 0 ? PPU : 0); jj++) {     \
-                const int j = ((HH) / PEVERY) * PPU + jj;                                       \
-                if (j < 4) PW[j] = bload4(rW_, DWP_OFF(T, j), 0);                               \
-                else PD[j - 4] = bload4(rD_, DWP_OFF(T, j - 4), 0);                             \
-            }                                                                                   \
-        }                                                                                       \
-    }
-#define DWP_MFMA(BUF)                                                                           \
-    {                                                                                           \
-        const float *ap = lds + (BUF)*8192 + h5 * 64 + 32 * wm + i;                             \
-        const float *bp = lds + (BUF)*8192 + 4096 + h5 * 64 + 32 * wn + i;                      \
-        float fa[32], fb[32]; /* static indices only: registers; DWP_INTERLEAVE decides how far ahead they are read */ \
-        _Pragma("unroll") for (int p = 0; p < 32; p++) {                                        \
-            fa[p] = ap[p * 128];                                                                \
-            fb[p] = bp[p * 128];                                                                \
-        }                                                                                       \
-        /* bias-only tiles (no weight rows) have nothing to multiply */                         \
-        if (!BO || DWP_ROWS(tc) != 0) { _Pragma("unroll") for (int p = 0; p < 32; p++) acc = mfma32(fa[p], fb[p], acc); } \
     }
     // bias gradient of the tile's columns: frames summed sequentially in fp32 (kernAccSumrow order,
     // DevFunc.cu:267-285 <- BP_GPU.cu:434); the dEdX unit is in LDS anyway
@@ -794,73 +784,56 @@ __device__ __forceinline__ void dwp_body(const DwpDesc *__restrict__ table, cons
             for (; b < bend; b++) bsum += col[b * 64];                                          \
         }                                                                                       \
     }
-#define DWP_UPDATE(BUF, PW, PD, DIVN)                                                               \
+    // bias update of the PREVIOUS tile (kernUpdatedelta with weightcost 0 + kernAccSum, BP_GPU.cu:435,437)
+    // (buffer accesses, not pointer dereferences: a generic pointer out of the record compiles to FLAT loads /
+    // stores, which return out of order and may alias LDS -- every later s_waitcnt in the tile then degrades to
+    // vmcnt(0) / lgkmcnt(0) and the pipeline of the unit blocks is gone)
+#define DWP_BIAS_UPDATE()                                                                       \
     {                                                                                           \
-        if (tid < DWP_NBIAS(tc)) {                                                              \
-            if (FUSED) { /* kernUpdatedelta with weightcost 0 + kernAccSum, BP_GPU.cu:435,437 */ \
-                const float bv = tc.bias[tid];                                                  \
-                const float d = mom * tc.dbias[tid] - lr * (DIVN(bsum) + 0.0f * bv);            \
-                tc.dbias[tid] = d;                                                              \
-                tc.bias[tid] = d + 1.0f * bv;                                                   \
+        if (tid < DWP_NBIAS(tp)) {                                                              \
+            const rsrc_t rb_ = make_rsrc(tp.bias, 256), rdb_ = make_rsrc(tp.dbias, FUSED ? 256 : 0); \
+            if (FUSED) {                                                                        \
+                const float bv = bload(rb_, tid * 4, 0);                                        \
+                const float d = mom * bload(rdb_, tid * 4, 0) - lr * (DWP_DIVN(bsum_p) + 0.0f * bv); \
+                bstore1(d, rdb_, tid * 4);                                                      \
+                bstore1(d + 1.0f * bv, rb_, tid * 4);                                           \
             } else {                                                                            \
-                tc.bias[tid] = bsum;                                                            \
+                bstore1(bsum_p, rb_, tid * 4);                                                  \
             }                                                                                   \
         }                                                                                       \
-        /* Transposition scratch without a workgroup barrier: the OTHER buffer is free (every wave finished        \
-           reading it before the barrier that ended the previous unit) and is about to be overwritten with the   \
-           next unit's operands; wave w's 32x32 scratch tile lives exactly in the 16 A-rows of that buffer that   \
-           wave w itself overwrites there (rows 4w..4w+3 of every group of 16: scratch word s -> row 4w + (s>>6&3) \
-           + 16*(s>>8), column s&63), so no other wave's data is touched and one wave's LDS operations are ordered */ \
-        float *Tw = lds + ((BUF) ^ 1) * 8192 + wave * 256;                                      \
-        _Pragma("unroll") for (int r = 0; r < 16; r++) {                                        \
+    }
+    // epilogue of the previous tile, piece by piece.  Scratch word s of wave w -> row 4w + (s>>6&3) + 16*(s>>8),
+    // column s&63 of the A half of buffer SB (the rows only wave w refills).
+#define DWP_EPI_SCRATCH_WRITE(SB, R0, R1)                                                       \
+    {                                                                                           \
+        float *Tw = lds + (SB)*8192 + wave * 256;                                               \
+        _Pragma("unroll") for (int r = (R0); r < (R1); r++) {                                   \
             const int kl = acc_row(r, lane);                                                    \
-            Tw[(kl >> 3) * 1024 + ((kl >> 1) & 3) * 64 + (kl & 1) * 32 + i] = acc[r];           \
+            Tw[(kl >> 3) * 1024 + ((kl >> 1) & 3) * 64 + (kl & 1) * 32 + i] = accp[r];          \
         }                                                                                       \
-        __builtin_amdgcn_wave_barrier();                                                        \
-        const rsrc_t rWc = make_rsrc(tc.W, tc.szW), rDc = make_rsrc(tc.D, FUSED ? tc.szW : 0);  \
-        _Pragma("unroll") for (int it = 0; it < 4; it++) {                                      \
-            const float4 g = *reinterpret_cast<const float4 *>(Tw + it * 1024 + (er >> 1) * 64 + (er & 1) * 32 + 4 * ec); \
-            const int off = DWP_OFF(tc, it);                                                    \
-            if (FUSED) { /* kernUpdatedelta (DevFunc.cu:502) then kernAccSum (DevFunc.cu:440) */ \
-                const float4 w = PW[it];                                                        \
-                float4 d = PD[it];                                                              \
-                d.x = mom * d.x - lr * (DIVN(g.x) + wc * w.x);                                   \
-                d.y = mom * d.y - lr * (DIVN(g.y) + wc * w.y);                                   \
-                d.z = mom * d.z - lr * (DIVN(g.z) + wc * w.z);                                   \
-                d.w = mom * d.w - lr * (DIVN(g.w) + wc * w.w);                                   \
-                bstore4(d, rDc, off);                                                           \
-                bstore4(make_float4(d.x + 1.0f * w.x, d.y + 1.0f * w.y, d.z + 1.0f * w.z, d.w + 1.0f * w.w), rWc, off); \
-            } else {                                                                            \
-                bstore4(g, rWc, off);                                                           \
-            }                                                                                   \
-        }                                                                                       \
-        _Pragma("unroll") for (int r = 0; r < 16; r++) acc[r] = 0.0f;                           \
     }
-#define DWP_DIV_EXACT(x) ((x) / nf)
-#define DWP_DIV_POW2(x) ((x) * inv_nf)
-#define DWP_EPILOGUE(BUF, PW, PD)                                                               \
+    // (the empty asm pins the read to the group it is written in: left alone, the compiler sinks the LDS load down
+    // to its first use two groups later and then waits for it with lgkmcnt(0) in front of an MFMA)
+#define DWP_EPI_SCRATCH_READ(SB, IT)                                                            \
     {                                                                                           \
-        if (nf_pow2) DWP_UPDATE(BUF, PW, PD, DWP_DIV_POW2)                                      \
-        else DWP_UPDATE(BUF, PW, PD, DWP_DIV_EXACT)                                             \
+        gq[IT] = *reinterpret_cast<const float4 *>(lds + (SB)*8192 + wave * 256 + (IT)*1024 + (er >> 1) * 64 + (er & 1) * 32 + 4 * ec); \
+        asm volatile("" : "+v"(gq[IT].x), "+v"(gq[IT].y), "+v"(gq[IT].z), "+v"(gq[IT].w));     \
     }
-    // Issue order inside a unit (one basic block: the unit's vector loads, its 32 LDS fragment-read pairs and its
-    // 32 MFMAs).  The fragments of two MFMA pairs are read ahead, then every group is {2 MFMAs, the fragment reads of
-    // the pair after next, one vector load}: an MFMA never waits for an LDS read issued just before it, and the
-    // 8 + PPU vector loads are spread between the MFMAs instead of ahead of them -- after a barrier all waves of the
-    // CU issue their loads at once and each waited ~0.7 us in the memory pipeline's queue before its first MFMA
-    // (MFMA and memory work only overlap when interleaved in ONE wave's stream: profiles/r01_overlap_probe.txt).
-#define DWP_INTERLEAVE()                                                                        \
+#define DWP_EPI_UPDATE(PW, PD, IT)                                                              \
     {                                                                                           \
-        if (interleave) {                                                                       \
-            constexpr int NV = 8 + (FUSED ? PPU : 0);                                           \
-            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                  \
-            _Pragma("unroll") for (int g = 0; g < 14; g++) {                                    \
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                              \
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                              \
-                if (g + 14 < NV) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);             \
-                else if (g < NV) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);             \
-            }                                                                                   \
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                  \
+        const float4 gv_ = gq[IT];                                                                \
+        const int off = DWP_OFF(tp, IT);                                                        \
+        if (FUSED) { /* kernUpdatedelta (DevFunc.cu:502) then kernAccSum (DevFunc.cu:440) */    \
+            const float4 w = PW[IT];                                                            \
+            float4 d = PD[IT];                                                                  \
+            d.x = mom * d.x - lr * (DWP_DIVN(gv_.x) + wc * w.x);                                  \
+            d.y = mom * d.y - lr * (DWP_DIVN(gv_.y) + wc * w.y);                                  \
+            d.z = mom * d.z - lr * (DWP_DIVN(gv_.z) + wc * w.z);                                  \
+            d.w = mom * d.w - lr * (DWP_DIVN(gv_.w) + wc * w.w);                                  \
+            bstore4(d, rDp, off);                                                               \
+            bstore4(make_float4(d.x + 1.0f * w.x, d.y + 1.0f * w.y, d.z + 1.0f * w.z, d.w + 1.0f * w.w), rWp, off); \
+        } else {                                                                                \
+            bstore4(gv_, rWp, off);                                                               \
         }                                                                                       \
     }
     long long ph_sum[5] = {0, 0, 0, 0, 0}, ph_last = 0;
@@ -874,44 +847,142 @@ __device__ __forceinline__ void dwp_body(const DwpDesc *__restrict__ table, cons
             __builtin_amdgcn_sched_barrier(0);                                                  \
         }                                                                                       \
     }
-    // one tile whose first unit sits in LDS buffer BASE: PWC/PDC = this tile's W/delta registers,
-    // PWN/PDN = the next tile's (an invalid next tile has empty descriptors: its loads cost nothing)
-#define DWP_TILE(PWC, PDC, PWN, PDN, BASE)                                                      \
+    // One 64-frame unit HH of the current tile, whose operands sit in LDS buffer BUF; the next unit's operands
+    // (unit HH+1 of this tile, or unit 0 of the next) go to the other buffer.  PW / PD: the register set the pending
+    // epilogue consumes (first unit) and the NEXT tile's W / delta are then loaded into (last unit).
+#define DWP_UNIT(HH, BUF, PW, PD)                                                               \
     {                                                                                           \
-        tnn_raw = DWP_FETCH(t + 2 * nblocks); /* in flight until the end of this tile */        \
-        _Pragma("unroll") for (int hh = 0; hh < H; hh++) {                                      \
-            const int buf = ((BASE) + hh) & 1;                                                  \
-            DWP_BIAS(buf, hh)                                                                   \
-            if (hh + 1 < H) DWP_LOAD_UNIT(tc, hh + 1)                                           \
-            else DWP_LOAD_UNIT(tn, 0)                                                           \
-            DWP_PREFETCH(PWN, PDN, tn, hh)                                                      \
-            DWP_MFMA(buf)                                                                       \
-            DWP_INTERLEAVE()                                                                    \
-            DWP_PHASE(hh == H - 1 ? 2 : 0)                                                      \
-            if (hh == H - 1) {                                                                  \
-                DWP_EPILOGUE(buf, PWC, PDC)                                                     \
-                DWP_PHASE(3)                                                                    \
-            }                                                                                   \
-            DWP_WRITE_UNIT(buf ^ 1)                                                             \
-            __syncthreads();                                                                    \
-            DWP_PHASE(hh == H - 1 ? 4 : 1)                                                      \
+        const bool FIRSTU = (HH) == 0, LASTU = (HH) == H - 1; /* constants once the unit loop is unrolled */ \
+        DWP_BIAS(BUF, HH)                                                                       \
+        if (FIRSTU) DWP_BIAS_UPDATE()                                                           \
+        /* ---- one basic block from here to the barrier ---- */                                \
+        const rsrc_t rA_ = LASTU ? make_rsrc(tn.A, DWP_SZAB(tn)) : make_rsrc(tc.A, DWP_SZAB(tc)); \
+        const rsrc_t rB_ = LASTU ? make_rsrc(tn.Bm, DWP_SZAB(tn)) : make_rsrc(tc.Bm, DWP_SZAB(tc)); \
+        const int ldA_ = LASTU ? tn.ldA : tc.ldA, ldB_ = LASTU ? tn.Np : tc.Np;                 \
+        const int row0_ = LASTU ? 0 : 64 * ((HH) + 1);                                          \
+        const rsrc_t rWn = make_rsrc(tn.W, tn.szW), rDn = make_rsrc(tn.D, FUSED ? tn.szW : 0);  \
+        const rsrc_t rWp = make_rsrc(tp.W, tp.szW), rDp = make_rsrc(tp.D, FUSED ? tp.szW : 0);  \
+        const float *ap = lds + (BUF)*8192 + h5 * 64 + 32 * wm + i;                             \
+        const float *bp = lds + (BUF)*8192 + 4096 + h5 * 64 + 32 * wn + i;                      \
+        float fa[32], fb[32]; /* static indices only: registers */                              \
+        float4 gq[4];                                                                           \
+        _Pragma("unroll") for (int p = 0; p < 4; p++) {                                         \
+            fa[p] = (ABL & 8) ? 1.0f : ap[p * 128];                                             \
+            fb[p] = (ABL & 8) ? 1.0f : bp[p * 128];                                             \
         }                                                                                       \
+        if (FIRSTU) tnn_raw = DWP_FETCH(t + 2 * nblocks);                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+        _Pragma("unroll") for (int g = 0; g < 16; g++) {                                        \
+            if (!(ABL & 12)) {                                                                  \
+                acc = mfma32(fa[2 * g], fb[2 * g], acc);                                        \
+                acc = mfma32(fa[2 * g + 1], fb[2 * g + 1], acc);                                \
+            } else if (!(ABL & 8)) {                                                            \
+                asm volatile("" ::"v"(fa[2 * g]), "v"(fb[2 * g]), "v"(fa[2 * g + 1]), "v"(fb[2 * g + 1])); \
+            }                                                                                   \
+            if (g < 14 && !(ABL & 8)) {                                                         \
+                _Pragma("unroll") for (int p = 2 * g + 4; p < 2 * g + 6; p++) {                 \
+                    fa[p] = ap[p * 128];                                                        \
+                    fb[p] = bp[p * 128];                                                        \
+                }                                                                               \
+            }                                                                                   \
+            /* operands of the next unit: one 16-byte load per group -- two per group in the unit that carries the     \
+               pending epilogue, so that all of them are OLDER than its stores (groups 4..10): s_waitcnt vmcnt counts  \
+               in issue order, and the hand-off below must not have to wait for a store to be acknowledged */          \
+            if (!(ABL & 16) && (FIRSTU ? g < 4 : g < 8)) {                                       \
+                const int q = FIRSTU ? g : g >> 1, row = row0_ + srow + 16 * q;                  \
+                if (FIRSTU || (g & 1) == 0) ra[q] = bload4(rA_, (row * ldA_ + 4 * scol) * 4, 0); \
+                if (FIRSTU || (g & 1) == 1) rb[q] = bload4(rB_, (row * ldB_ + 4 * scol) * 4, 0); \
+            }                                                                                   \
+            /* epilogue of the previous tile: accumulators -> scratch (groups 0, 1), read back (float4 IT in group    \
+               2 + IT), update + stores (group 4 + 2 IT: every read is at least two groups old when it is used) */ \
+            if (FIRSTU) {                                                                       \
+                if (g == 0) DWP_EPI_SCRATCH_WRITE((BUF) ^ 1, 0, 8)                              \
+                if (g == 1) {                                                                   \
+                    DWP_EPI_SCRATCH_WRITE((BUF) ^ 1, 8, 16)                                     \
+                    __builtin_amdgcn_wave_barrier();                                            \
+                }                                                                               \
+                if (g >= 2 && g <= 5) DWP_EPI_SCRATCH_READ((BUF) ^ 1, g - 2)                    \
+                if (g >= 4 && g <= 10 && (g & 1) == 0 && !(ABL & 1)) DWP_EPI_UPDATE(PW, PD, (g - 4) >> 1) \
+            }                                                                                   \
+            /* W / delta of the NEXT tile, consumed by its epilogue a whole tile later: into the set the pending       \
+               epilogue has just used (groups 12..15 when this unit is both first and last, else one load per group    \
+               8..15) */                                                                        \
+            if (FUSED && LASTU && !(ABL & 2)) {                                                 \
+                if (FIRSTU) {                                                                   \
+                    if (g >= 12) {                                                              \
+                        PW[g - 12] = bload4(rWn, DWP_OFF(tn, g - 12), 0);                       \
+                        PD[g - 12] = bload4(rDn, DWP_OFF(tn, g - 12), 0);                       \
+                    }                                                                           \
+                } else if (g >= 8) {                                                            \
+                    if (g < 12) PW[g - 8] = bload4(rWn, DWP_OFF(tn, g - 8), 0);                 \
+                    else PD[g - 12] = bload4(rDn, DWP_OFF(tn, g - 12), 0);                      \
+                }                                                                               \
+            }                                                                                   \
+            __builtin_amdgcn_sched_barrier(0);                                                  \
+        }                                                                                       \
+        DWP_PHASE(LASTU ? 2 : 0)                                                                \
+        if (!(ABL & 32)) DWP_WRITE_UNIT((BUF) ^ 1)                                              \
+        __syncthreads();                                                                        \
+        DWP_PHASE(LASTU ? 4 : 1)                                                                \
+    }
+    // one tile whose first unit sits in LDS buffer BASE
+#define DWP_TILE(BASE, PW, PD)                                                                  \
+    {                                                                                           \
+        _Pragma("unroll") for (int hh = 0; hh < H; hh++) DWP_UNIT(hh, ((BASE) + hh) & 1, PW, PD) \
+        /* the tile's accumulators, bias sum and record become "previous": their epilogue rides in the next tile */ \
+        accp = acc;                                                                             \
+        _Pragma("unroll") for (int r = 0; r < 16; r++) acc[r] = 0.0f;                           \
+        bsum_p = bsum;                                                                          \
+        tp = tc;                                                                                \
         t += nblocks;                                                                           \
         if (t >= total) break;                                                                  \
         tc = tn;                                                                                \
         tn = dwp_decode(tnn_raw);                                                               \
     }
 
-    // prologue: first unit into buffer 0, this tile's W/delta into set 0
-    DWP_LOAD_UNIT(tc, 0)
-    _Pragma("unroll") for (int hh = 0; hh < H; hh++) DWP_PREFETCH(pw0, pd0, tc, hh)
+    // prologue: first unit into buffer 0, the first tile's W / delta into set 0
+    {
+        const rsrc_t rA_ = make_rsrc(tc.A, DWP_SZAB(tc)), rB_ = make_rsrc(tc.Bm, DWP_SZAB(tc));
+        const rsrc_t rWc = make_rsrc(tc.W, tc.szW), rDc = make_rsrc(tc.D, FUSED ? tc.szW : 0);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int row = srow + 16 * q;
+            ra[q] = bload4(rA_, (row * tc.ldA + 4 * scol) * 4, 0);
+            rb[q] = bload4(rB_, (row * tc.Np + 4 * scol) * 4, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            pw0[q] = FUSED ? bload4(rWc, DWP_OFF(tc, q), 0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            pd0[q] = FUSED ? bload4(rDc, DWP_OFF(tc, q), 0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
     DWP_WRITE_UNIT(0)
     __syncthreads();
     if (PHASES) ph_last = (long long)__builtin_amdgcn_s_memtime();
     // a tile of H units leaves its successor's first unit in buffer (BASE + H) & 1
+    // tile k of this workgroup: its pending epilogue (tile k-1) consumes set (k-1) & 1, which its last unit refills
+    // with tile k+1's W / delta; set k & 1 (loaded during tile k-1, or in the prologue) waits for tile k+1
+    bool last_set1 = true;
     for (;;) {
-        DWP_TILE(pw0, pd0, pw1, pd1, 0)
-        DWP_TILE(pw1, pd1, pw0, pd0, H & 1)
+        last_set1 = false;  // the tile that ends the walk here leaves ITS W / delta in set 0
+        DWP_TILE(0, pw1, pd1)
+        last_set1 = true;
+        DWP_TILE(H & 1, pw0, pd0)
+    }
+    // epilogue of the last tile (tp): nothing left to hide it behind.  Both operand buffers are dead (every wave has
+    // passed the last unit's barrier) and the scratch rows are wave-private.
+    {
+        DWP_BIAS_UPDATE()
+        const rsrc_t rWp = make_rsrc(tp.W, tp.szW), rDp = make_rsrc(tp.D, FUSED ? tp.szW : 0);
+        float4 gq[4];
+        DWP_EPI_SCRATCH_WRITE(0, 0, 16)
+        __builtin_amdgcn_wave_barrier();
+        _Pragma("unroll") for (int it = 0; it < 4; it++) DWP_EPI_SCRATCH_READ(0, it)
+        if (last_set1) {
+            _Pragma("unroll") for (int it = 0; it < 4; it++) DWP_EPI_UPDATE(pw1, pd1, it)
+        } else {
+            _Pragma("unroll") for (int it = 0; it < 4; it++) DWP_EPI_UPDATE(pw0, pd0, it)
+        }
     }
     stamp_clk(stamps, 2, bid);
     if (stamps != nullptr && threadIdx.x == 0) stamps[(size_t)bid * 8 + 4] = (t - bid) / nblocks;  // tiles walked
@@ -921,22 +992,20 @@ __device__ __forceinline__ void dwp_body(const DwpDesc *__restrict__ table, cons
     }
 #undef DWP_PHASE
 #undef DWP_FETCH
-#undef DWP_LOAD_UNIT
 #undef DWP_WRITE_UNIT
 #undef DWP_OFF
-#undef DWP_PREFETCH
-#undef DWP_MFMA
 #undef DWP_BIAS
-#undef DWP_EPILOGUE
-#undef DWP_UPDATE
-#undef DWP_DIV_EXACT
-#undef DWP_DIV_POW2
+#undef DWP_BIAS_UPDATE
+#undef DWP_EPI_SCRATCH_WRITE
+#undef DWP_EPI_SCRATCH_READ
+#undef DWP_EPI_UPDATE
+#undef DWP_UNIT
 #undef DWP_TILE
-#undef DWP_INTERLEAVE
 #undef DWP_ROWS
 #undef DWP_COLS
 #undef DWP_NBIAS
 #undef DWP_SZAB
+#undef DWP_DIVN
 }
 
 // ---------------------------------------------------------------------------------------
@@ -957,14 +1026,19 @@ template <int NW>
 __global__ __launch_bounds__(64 * NW) void k_dx(DxArgs A, long long *stamps) {
     dx_body<NW>(A, (int)blockIdx.x, g_dyn_lds, stamps);
 }
-template <int H, bool FUSED, bool BO = false>
+template <int H, bool FUSED, bool POW2>
 __global__ __launch_bounds__(256) void k_dwp(const DwpDesc *__restrict__ table, int total, DwpConst C, long long *stamps) {
-    dwp_body<H, FUSED, BO>(table, total, C, (int)blockIdx.x, (int)gridDim.x, g_dyn_lds, stamps);
+    dwp_body<H, FUSED, POW2>(table, total, C, (int)blockIdx.x, (int)gridDim.x, g_dyn_lds, stamps);
 }
-// diagnostic twin of k_dwp<H, true> with the per-phase cycle sums (never launched unless asked for)
+// timing-only ablation twins (never launched unless MLGGD_DWP_ABLATE asks for one)
+template <int H, int ABL>
+__global__ __launch_bounds__(256) void k_dwp_ablate(const DwpDesc *__restrict__ table, int total, DwpConst C, long long *stamps) {
+    dwp_body<H, true, true, false, ABL>(table, total, C, (int)blockIdx.x, (int)gridDim.x, g_dyn_lds, stamps);
+}
+// diagnostic twin of k_dwp<H, true, true> with the per-phase cycle sums (never launched unless asked for)
 template <int H>
 __global__ __launch_bounds__(256) void k_dwp_phases(const DwpDesc *__restrict__ table, int total, DwpConst C, long long *stamps) {
-    dwp_body<H, true, false, true, true>(table, total, C, (int)blockIdx.x, (int)gridDim.x, g_dyn_lds, stamps);
+    dwp_body<H, true, true, true>(table, total, C, (int)blockIdx.x, (int)gridDim.x, g_dyn_lds, stamps);
 }
 // Elementwise update from an (all-reduced) gradient, data-parallel path.  Pad entries have
 // G = delta = W = 0 and stay 0.  kernUpdatedelta + kernAccSum, DevFunc.cu:490-507,427-443.
