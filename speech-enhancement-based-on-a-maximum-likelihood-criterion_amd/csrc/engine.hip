@@ -45,23 +45,32 @@ static int fail(int code, const char *fmt, ...) {
 static inline int ceil32(int x) { return (x + 31) & ~31; }
 
 // ------------------------------------------------------------------ RCCL (loaded on demand)
-// Only the data-parallel path needs RCCL; it is dlopen'ed at mlggd_comm_init so a single-GPU
-// process never maps it.  Types per rccl.h (ncclUniqueId = 128 opaque bytes, ncclFloat = 7,
-// ncclSum = 0).
-struct RcclUniqueId {
-    char internal[128];
-};
-typedef void *RcclComm;
+// Only the data-parallel path needs RCCL; it is dlopen'ed at mlggd_comm_init so a single-GPU process never maps
+// it.  The function-pointer types are taken from rccl.h itself (decltype of the declarations; the header is only
+// compiled against, nothing is linked), so a signature change in the library breaks the build, not a multi-GPU run.
+#include <rccl/rccl.h>
+static_assert(sizeof(ncclUniqueId) == MLGGD_UNIQUE_ID_BYTES, "include/mlggd.h MLGGD_UNIQUE_ID_BYTES != sizeof(ncclUniqueId)");
+typedef ncclUniqueId RcclUniqueId;
+typedef ncclComm_t RcclComm;
 struct RcclApi {
     void *lib = nullptr;
-    int (*GetUniqueId)(RcclUniqueId *) = nullptr;
-    int (*CommInitRank)(RcclComm *, int, RcclUniqueId, int) = nullptr;
-    int (*AllReduce)(const void *, void *, size_t, int, int, RcclComm, hipStream_t) = nullptr;
-    int (*CommDestroy)(RcclComm) = nullptr;
-    const char *(*GetErrorString)(int) = nullptr;
-    int (*AllGather)(const void *, void *, size_t, int, RcclComm, hipStream_t) = nullptr;
-    int (*GroupStart)() = nullptr;
-    int (*GroupEnd)() = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclAllReduce) AllReduce_ = nullptr;
+    decltype(&ncclAllGather) AllGather_ = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString_ = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    // fp32 sum / fp32 gather, the only forms the engine uses (the int arguments of the call sites are ignored: they
+    // date from the hand-written prototypes and are kept so the call sites read like the NCCL API)
+    int AllReduce(const void *s, void *r, size_t n, int, int, RcclComm c, hipStream_t st) const {
+        return (int)AllReduce_(s, r, n, ncclFloat32, ncclSum, c, st);
+    }
+    int AllGather(const void *s, void *r, size_t n, int, RcclComm c, hipStream_t st) const {
+        return (int)AllGather_(s, r, n, ncclFloat32, c, st);
+    }
+    const char *GetErrorString(int rc) const { return GetErrorString_ ? GetErrorString_((ncclResult_t)rc) : "rccl error"; }
 };
 static RcclApi g_rccl;
 static int rccl_load() {
@@ -73,16 +82,15 @@ static int rccl_load() {
         if (lib) break;
     }
     if (!lib) return fail(MLGGD_ERR_COMM, "cannot dlopen librccl: %s", dlerror());
-    g_rccl.GetUniqueId = (int (*)(RcclUniqueId *))dlsym(lib, "ncclGetUniqueId");
-    g_rccl.CommInitRank = (int (*)(RcclComm *, int, RcclUniqueId, int))dlsym(lib, "ncclCommInitRank");
-    g_rccl.AllReduce =
-        (int (*)(const void *, void *, size_t, int, int, RcclComm, hipStream_t))dlsym(lib, "ncclAllReduce");
-    g_rccl.AllGather = (int (*)(const void *, void *, size_t, int, RcclComm, hipStream_t))dlsym(lib, "ncclAllGather");
-    g_rccl.CommDestroy = (int (*)(RcclComm))dlsym(lib, "ncclCommDestroy");
-    g_rccl.GetErrorString = (const char *(*)(int))dlsym(lib, "ncclGetErrorString");
-    g_rccl.GroupStart = (int (*)())dlsym(lib, "ncclGroupStart");
-    g_rccl.GroupEnd = (int (*)())dlsym(lib, "ncclGroupEnd");
-    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.AllGather || !g_rccl.CommDestroy ||
+    g_rccl.GetUniqueId = (decltype(&ncclGetUniqueId))dlsym(lib, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (decltype(&ncclCommInitRank))dlsym(lib, "ncclCommInitRank");
+    g_rccl.AllReduce_ = (decltype(&ncclAllReduce))dlsym(lib, "ncclAllReduce");
+    g_rccl.AllGather_ = (decltype(&ncclAllGather))dlsym(lib, "ncclAllGather");
+    g_rccl.CommDestroy = (decltype(&ncclCommDestroy))dlsym(lib, "ncclCommDestroy");
+    g_rccl.GetErrorString_ = (decltype(&ncclGetErrorString))dlsym(lib, "ncclGetErrorString");
+    g_rccl.GroupStart = (decltype(&ncclGroupStart))dlsym(lib, "ncclGroupStart");
+    g_rccl.GroupEnd = (decltype(&ncclGroupEnd))dlsym(lib, "ncclGroupEnd");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce_ || !g_rccl.AllGather_ || !g_rccl.CommDestroy ||
         !g_rccl.GroupStart || !g_rccl.GroupEnd)
         return fail(MLGGD_ERR_COMM, "librccl is missing required symbols");
     g_rccl.lib = lib;
@@ -92,8 +100,7 @@ static int rccl_load() {
     do {                                                                                           \
         int _r = (expr);                                                                           \
         if (_r != 0)                                                                               \
-            return fail(MLGGD_ERR_COMM, "%s failed: %s", #expr,                                    \
-                        g_rccl.GetErrorString ? g_rccl.GetErrorString(_r) : "rccl error");          \
+            return fail(MLGGD_ERR_COMM, "%s failed: %s", #expr, g_rccl.GetErrorString(_r));        \
     } while (0)
 
 // ------------------------------------------------------------------ engine state
@@ -647,7 +654,7 @@ static int launch_dwp_t(mlggd_engine *e, const DwpJobs &J, bool fused, hipStream
         launch_timed(e, k_dwp_ablate<H, A_>, dim3(grid), dim3(256), lds, st, table, J.total, C, stamps);  \
         return launch_check("k_dwp_ablate");
             switch (abl) {
-                DWP_ABL(1) DWP_ABL(2) DWP_ABL(3) DWP_ABL(4) DWP_ABL(7) DWP_ABL(15) DWP_ABL(31) DWP_ABL(63) DWP_ABL(16) DWP_ABL(48)
+                DWP_ABL(1) DWP_ABL(2) DWP_ABL(3) DWP_ABL(4) DWP_ABL(7) DWP_ABL(15) DWP_ABL(31) DWP_ABL(63) DWP_ABL(16) DWP_ABL(48) DWP_ABL(64) DWP_ABL(128)
             default: return fail(MLGGD_ERR_ARG, "MLGGD_DWP_ABLATE=%d is not built", abl);
             }
 #undef DWP_ABL

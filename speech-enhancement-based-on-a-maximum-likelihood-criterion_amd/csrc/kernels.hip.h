@@ -888,10 +888,11 @@ __device__ __forceinline__ void dwp_body(const DwpDesc *__restrict__ table, cons
             /* operands of the next unit: one 16-byte load per group -- two per group in the unit that carries the     \
                pending epilogue, so that all of them are OLDER than its stores (groups 4..10): s_waitcnt vmcnt counts  \
                in issue order, and the hand-off below must not have to wait for a store to be acknowledged */          \
-            if (!(ABL & 16) && (FIRSTU ? g < 4 : g < 8)) {                                       \
-                const int q = FIRSTU ? g : g >> 1, row = row0_ + srow + 16 * q;                  \
-                if (FIRSTU || (g & 1) == 0) ra[q] = bload4(rA_, (row * ldA_ + 4 * scol) * 4, 0); \
-                if (FIRSTU || (g & 1) == 1) rb[q] = bload4(rB_, (row * ldB_ + 4 * scol) * 4, 0); \
+            if (!(ABL & 16) && ((FIRSTU || (ABL & 128)) ? g < 4 : g < 8)) {                      \
+                const bool two_ = FIRSTU || (ABL & 128);                                        \
+                const int q = two_ ? g : g >> 1, row = row0_ + srow + 16 * q;                    \
+                if (two_ || (g & 1) == 0) ra[q] = bload4(rA_, (row * ldA_ + 4 * scol) * 4, 0);   \
+                if (two_ || (g & 1) == 1) rb[q] = bload4(rB_, (row * ldB_ + 4 * scol) * 4, 0);   \
             }                                                                                   \
             /* epilogue of the previous tile: accumulators -> scratch (groups 0, 1), read back (float4 IT in group    \
                2 + IT), update + stores (group 4 + 2 IT: every read is at least two groups old when it is used) */ \
@@ -918,10 +919,18 @@ __device__ __forceinline__ void dwp_body(const DwpDesc *__restrict__ table, cons
                     else PD[g - 12] = bload4(rDn, DWP_OFF(tn, g - 12), 0);                      \
                 }                                                                               \
             }                                                                                   \
+            /* the next unit's operands go to LDS inside the block too (groups 12..15: their loads are 8+ groups old; \
+               the scratch of a pending epilogue in the same rows was read back in groups 2..5): after the block only \
+               the barrier is left (-3 % launch time against writing them after the last MFMA; ABL & 64 restores that) */ \
+            if (!(ABL & (32 | 64)) && g >= 12) {                                                \
+                float *as_ = lds + ((BUF) ^ 1) * 8192, *bs_ = as_ + 4096;                       \
+                *reinterpret_cast<float4 *>(as_ + (srow + 16 * (g - 12)) * 64 + 4 * scol) = ra[g - 12]; \
+                *reinterpret_cast<float4 *>(bs_ + (srow + 16 * (g - 12)) * 64 + 4 * scol) = rb[g - 12]; \
+            }                                                                                   \
             __builtin_amdgcn_sched_barrier(0);                                                  \
         }                                                                                       \
         DWP_PHASE(LASTU ? 2 : 0)                                                                \
-        if (!(ABL & 32)) DWP_WRITE_UNIT((BUF) ^ 1)                                              \
+        if ((ABL & 64) && !(ABL & 32)) DWP_WRITE_UNIT((BUF) ^ 1)                                \
         __syncthreads();                                                                        \
         DWP_PHASE(LASTU ? 4 : 1)                                                                \
     }

@@ -24,8 +24,11 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     eng.profile_select("dw", 0, 4096); eng.train_resident(0, NB * B); us, n = eng.profile_read(); eng.profile_select(None)
     print(json.dumps({"us": us, "n": n})); sys.exit(0)
 res = {}
-for rnd in range(2):
-    for abl in (0, 1, 2, 3, 4, 16, 48, 7, 15, 31, 63):
+names[64] = "operand LDS writes after the last MFMA instead of inside the block (correct results)"
+names[128] = "EXPERIMENT: operand loads two per group in groups 0..3 in every unit (correct results)"
+variants = [int(x) for x in sys.argv[1:]] or [0, 1, 2, 3, 4, 16, 48, 7, 15, 31, 63]
+for rnd in range(3 if len(variants) <= 3 else 2):
+    for abl in variants:
         env = dict(os.environ); env["MLGGD_DWP_ABLATE"] = str(abl)
         if abl == 0: env.pop("MLGGD_DWP_ABLATE")
         out = subprocess.run([sys.executable, __file__, "child"], env=env, capture_output=True, text=True)
