@@ -1157,7 +1157,7 @@ int mlggd_create(const mlggd_config *cfg, const float *const *weights, const flo
     if (cfg->bunchsize < 1) return fail(MLGGD_ERR_ARG, "bunchsize %d < 1", cfg->bunchsize);
     for (int i = 0; i < cfg->numlayers; i++)
         if (cfg->layersizes[i] < 1) return fail(MLGGD_ERR_ARG, "layersizes[%d] = %d", i, cfg->layersizes[i]);
-    if ((size_t)32 * (ceil32(cfg->bunchsize) + 1) * sizeof(float) > 150 * 1024)
+    if (ceil32(cfg->bunchsize) > 1152)  // LOSS_LDS_MAX: 32 columns x (1152 + 1) frames of the loss kernels' LDS tile
         return fail(MLGGD_ERR_ARG, "bunchsize %d too large for the loss kernel's LDS tile (max 1152)", cfg->bunchsize);
     int ndev = 0;
     hipError_t de = hipGetDeviceCount(&ndev);

@@ -126,7 +126,9 @@ static void phase(const char *name, double &t_last) {
 int main(int argc, char *argv[]) {
     const double t_start = (double)time(NULL);
     double t_phase = now_s();
-    printf("--------activation functin is sigmoid--------\n");  // BPtrain.cc:71
+    // BPtrain.cc:71: black on red when stdout is a terminal, as the reference prints it; plain text into pipes / logs
+    printf(isatty(STDOUT_FILENO) ? "\033[41;30m--------activation functin is sigmoid--------\033[0m\n"
+                                 : "--------activation functin is sigmoid--------\n");
     const int world = env_int("WORLD_SIZE", 1), rank = env_int("RANK", 0);
     const int local_rank = env_int("LOCAL_RANK", rank);
     Interface *io = new Interface;

@@ -90,6 +90,31 @@ def test_every_bunch_size_variant_of_the_dw_kernel(pkg, pyoracle, synth, B):
     eng.close()
 
 
+def test_largest_advertised_bunch_with_the_ml_loss(pkg, pyoracle, synth):
+    """mlggd_create accepts bunchsize up to 1152; the ML loss kernels then need 32*(Bp+1)+32 floats = 148 KB of
+    dynamic LDS (the attribute has to be raised past 64 KB: ADVICE r01).  B = 1024 and B = 1152 with MLflag=1, two
+    steps against the oracle (the dW kernel takes its non-persistent fallback at these sizes)."""
+    for B in (1024, 1152):
+        ls = [70, 130, 64, 33]
+        eng, ora = make_pair(pkg, pyoracle, synth, ls, B, 1, 1.2, seed=21)
+        inp, targ = synth.make_frames(2 * B + 7, 10, 7, seed=22)
+        targ = np.ascontiguousarray(np.tile(targ, (1, 4))[:, :33])
+        assert eng.train(inp, targ) == 2 and ora.train(inp, targ) == 2
+        we, be = eng.returnWeights()
+        wo, bo = ora.get_weights()
+        for l in range(len(we)):
+            assert relmax(we[l], wo[l]) < 2e-5, (B, l)
+            assert relmax(be[l], bo[l]) < 2e-5, (B, l)
+        assert relmax(eng.scalefactor(), ora.tensor("scalefactor")) < 1e-5
+        sq, ab, ll = eng.cv_all(inp, targ)
+        assert abs(ll - ora.cv_loglik(inp, targ)) <= 1e-4 * abs(ll)
+        eng.close()
+        ora.close()
+    with pytest.raises(pkg.MlggdError, match="too large"):
+        ws, bs = synth.make_weights([70, 130, 64, 33], seed=21)
+        pkg.BPGpu(1, 0, [70, 130, 64, 33], 1153, 0.1, 0.9, 0.0, ws, bs, 1.2, 1)
+
+
 @pytest.mark.parametrize("ml,beta", [(0, 2.0), (1, 1.2)])
 def test_baseline_net_two_steps(pkg, pyoracle, synth, ml, beta):
     """BASELINE.json configs 2/3: 2827-2048x3-257, 128-frame minibatch."""
