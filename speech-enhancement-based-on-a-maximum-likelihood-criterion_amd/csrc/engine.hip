@@ -633,6 +633,24 @@ static int launch_dwp_t(mlggd_engine *e, const DwpJobs &J, bool fused, hipStream
     C.mom = J.job[0].mom;
     C.lr = J.job[0].lr;
     C.wc = J.job[0].wc;
+    bool bias_only = J.njobs > 0, any_bias_only = false;  // only the sharded data-parallel plans hold bias-only jobs
+    for (int j = 0; j < J.njobs; j++) {
+        bias_only = bias_only && J.job[j].wd_off != 0;
+        any_bias_only = any_bias_only || J.job[j].wd_off != 0;
+    }
+    if (any_bias_only) {
+        if (!bias_only || !fused) return fail(MLGGD_ERR_STATE, "bias-only jobs need a launch of their own on the fused path");
+        unsigned nb;
+        memcpy(&nb, &C.nf, sizeof(nb));
+        if ((nb & 0x007FFFFFu) == 0u && C.nf >= 1.0f) {
+            CHK(ensure_lds(e, k_dwp_bias<H, true>, lds));
+            hipLaunchKernelGGL((k_dwp_bias<H, true>), dim3(grid), dim3(256), lds, st, table, J.total, C, (long long *)nullptr);
+        } else {
+            CHK(ensure_lds(e, k_dwp_bias<H, false>, lds));
+            hipLaunchKernelGGL((k_dwp_bias<H, false>), dim3(grid), dim3(256), lds, st, table, J.total, C, (long long *)nullptr);
+        }
+        return launch_check("k_dwp_bias");
+    }
     if constexpr (H == 2 || H == 8) {
         if (e->stamp_class == KC_DW && e->stamp_layer == -1 && e->stamp_buf && fused && C.nf == 128.0f) {
             // diagnostic: the twin kernel with per-phase cycle sums (rows grid .. 2*grid-1 of the stamp buffer)
@@ -766,15 +784,15 @@ static int shard_alloc(mlggd_engine *e) {
     HIPCHK(hipEventCreateWithFlags(&e->ev_dw_done, hipEventDisableTiming));
     return MLGGD_OK;
 }
-// jobs of (virtual) rank r; with_bias_only: also the bias-only jobs of the layers whose row block 0 it
-// does not own; own_bias: whether its own row-block-0 job applies the bias update
-static DwpJobs dwp_jobs_shard(mlggd_engine *e, float nf, int r, bool with_bias_only, bool own_bias) {
+// jobs of (virtual) rank r.  pass 0: its row blocks of every layer (own_bias: whether its own row-block-0 job
+// applies the bias update); pass 1: the bias-only jobs of the layers whose row block 0 it does not own -- a
+// separate launch of the bias-only kernel (k_dwp_bias)
+static DwpJobs dwp_jobs_shard(mlggd_engine *e, float nf, int r, int pass, bool own_bias) {
     DwpJobs G = dwp_jobs(e, e->L - 1, 1, e->Yall[0], nf), J;
     memset(&J, 0, sizeof(J));
     int nj = 0, end = 0;
-    // the full tiles first, the cheap bias-only tiles last: a workgroup that has to take a second tile
-    // then takes a cheap one
-    for (int pass = 0; pass < 2; pass++)
+    {
+        const bool with_bias_only = true;
         for (int j = 0; j < G.njobs; j++) {
             const int l = e->L - 1 - j;
             DwpArgs a = G.job[j];
@@ -800,6 +818,7 @@ static DwpJobs dwp_jobs_shard(mlggd_engine *e, float nf, int r, bool with_bias_o
             end += a.ntiles;
             J.tile_end[nj++] = end;
         }
+    }
     J.njobs = nj;
     J.total = end;
     return J;
@@ -1065,15 +1084,20 @@ static int run_step(mlggd_engine *e, int sample0, bool prestaged = false, const 
             const char *only = getenv("MLGGD_FAKE_ONLY_RANK");  // timing: run one rank's share only (tools/dp_sim.py)
             for (int r = 0; r < e->world; r++) {
                 if (only && atoi(only) != r) continue;
-                DwpJobs J = only ? dwp_jobs_shard(e, nf, r, true, true)
-                                 : dwp_jobs_shard(e, nf, r, r == e->world - 1, e->world == 1);
+                if (only || r == e->world - 1) {  // the bias update comes from the LAST rank's bias-only tiles
+                    DwpJobs Jb = dwp_jobs_shard(e, nf, r, 1, false);
+                    if (Jb.total > 0) CHK(launch_dwp(e, Jb, true, dws, 1, units));
+                }
+                DwpJobs J = dwp_jobs_shard(e, nf, r, 0, only ? true : e->world == 1);
                 ProfScope ps(e, KC_DW, 1, dws);
                 if (J.total > 0) CHK(launch_dwp(e, J, true, dws, 1, units));
             }
         } else {
             {
+                DwpJobs Jb = dwp_jobs_shard(e, nf, e->rank, 1, false);  // bias-only tiles: no W access, so they go first
+                if (Jb.total > 0) CHK(launch_dwp(e, Jb, true, dws, 1, units));
                 ProfScope ps(e, KC_DW, 1, dws);
-                DwpJobs J = dwp_jobs_shard(e, nf, e->rank, true, true);
+                DwpJobs J = dwp_jobs_shard(e, nf, e->rank, 0, true);
                 if (J.total > 0) CHK(launch_dwp(e, J, true, dws, 1, units));
             }
             HIPCHK(hipEventRecord(e->ev_dw_done, dws));

@@ -1039,6 +1039,15 @@ template <int H, bool FUSED, bool POW2>
 __global__ __launch_bounds__(256) void k_dwp(const DwpDesc *__restrict__ table, int total, DwpConst C, long long *stamps) {
     dwp_body<H, FUSED, POW2>(table, total, C, (int)blockIdx.x, (int)gridDim.x, g_dyn_lds, stamps);
 }
+// Bias-only tiles (sharded data parallel: the tiles of weight-row block 0 on the ranks that do not own it, so that
+// every rank applies the identical bias update without another collective): the same walk with everything but the
+// operand staging and the bias gradient / update compiled out -- no W / delta access, no fragment reads, no MFMAs.
+// They get a launch of their own: inside the main launch the skip would be a branch around the MFMAs, which splits
+// the unit blocks and undoes the interleave for every tile (what slowed the round-1 kernel down).
+template <int H, bool POW2>
+__global__ __launch_bounds__(256) void k_dwp_bias(const DwpDesc *__restrict__ table, int total, DwpConst C, long long *stamps) {
+    dwp_body<H, true, POW2, false, 15>(table, total, C, (int)blockIdx.x, (int)gridDim.x, g_dyn_lds, stamps);
+}
 // timing-only ablation twins (never launched unless MLGGD_DWP_ABLATE asks for one)
 template <int H, int ABL>
 __global__ __launch_bounds__(256) void k_dwp_ablate(const DwpDesc *__restrict__ table, int total, DwpConst C, long long *stamps) {
