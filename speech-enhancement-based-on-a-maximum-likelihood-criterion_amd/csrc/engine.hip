@@ -871,8 +871,9 @@ static int run_loss(mlggd_engine *e, const Bunch &bn, float nf, float inv_n, Col
                     const StageArgs &sa, int n_stage) {
     const int L = e->L, B = e->B, Bp = e->Bp, b_tiles = Bp / 32, ML = e->cfg.MLflag;
     ProfScope ps(e, KC_LOSS, 0);
-    const size_t lds = (size_t)(32 * (Bp + 1) + 32) * sizeof(float);
-    const int n_loss = (e->Dp / 32) * b_tiles;
+    const size_t lds = (size_t)(32 * (Bp + 1) + 32) * sizeof(float);               // k_colsum: 32 columns per workgroup
+    const size_t lds_grad = (size_t)(LOSS_DT * (Bp + 1) + LOSS_DT) * sizeof(float);  // k_loss_grad: LOSS_DT columns
+    const int n_loss = (e->Dp / LOSS_DT) * b_tiles;  // 8 (d) x 32 (b) elements per loss workgroup, one per thread
     if (ML != 1 && e->loss_fuse) {
         if (cs == CS_ACCUMULATE) return MLGGD_OK;  // no minibatch statistic without the ML loss
         LossNormArgs la;
@@ -908,7 +909,7 @@ static int run_loss(mlggd_engine *e, const Bunch &bn, float nf, float inv_n, Col
     }
     if (cs == CS_ACCUMULATE) return MLGGD_OK;
     CHK(ensure_lds(e, k_loss_grad, LOSS_LDS_MAX));
-    hipLaunchKernelGGL(k_loss_grad, dim3(n_loss), dim3(256), lds, e->stream, e->eT, e->pT, colsum_in, B, e->D, e->Dp, Bp,
+    hipLaunchKernelGGL(k_loss_grad, dim3(n_loss), dim3(256), lds_grad, e->stream, e->eT, e->pT, colsum_in, B, e->D, e->Dp, Bp,
                        e->cfg.shapefactor, ML, nf, inv_n, e->scalefactor, e->dEdXt[L - 1], e->dEdX[L - 1], b_tiles);
     return launch_check("k_loss_grad");
 }

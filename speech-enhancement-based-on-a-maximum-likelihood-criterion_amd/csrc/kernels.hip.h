@@ -1189,12 +1189,20 @@ __device__ __forceinline__ float slab_sum(const float *__restrict__ slab, size_t
 }
 
 // ---------------------------------------------------------------------------------------
-// Output-layer loss, phase A (elementwise, one workgroup per 32(d) x 32(b) tile):
-//   out = bias + sum_s slab[s];  e = out - targ;  p = |e|^beta
-// kernerror, kernabsolutevalus, kernindex2 (DevFunc.cu:399-409,186-191,219-227 <-
-// BP_GPU.cu:413-415).  Writes outT, eT, pT, all [Dp][Bp] with zeros in the pads.  targ is the
-// caller's row-major [B][D]; it is read in 128-byte row segments and transposed through LDS.
+// Output-layer loss kernels.  One workgroup = 8 output units (d) x 32 frames (b), ONE element per thread, lanes
+// along the frames: the slab / outT / eT / pT / dEdXt rows are read and written in 128-byte segments; targ and
+// the row-major dEdX are touched in 32-byte pieces (they are 0.13 MB per step).  Round 1 used 32 x 32 tiles with
+// four elements per thread: 36 workgroups whose threads each ran four slab sums and four powf one after the other
+// -- 8 us of pure latency for 33k elements; with 144 workgroups the chain is a quarter as long.
+// pow(x, 1.0f) is x itself for every float (IEEE 754 / C99 F.9.4.4), so the MMSE case (beta - 1 = 1) skips the
+// call: same bits, no powf on that path.
 // ---------------------------------------------------------------------------------------
+constexpr int LOSS_DT = 8;  // output units per loss workgroup
+__device__ __forceinline__ float pow_or_self(float x, float p) { return p == 1.0f ? x : powf(x, p); }
+
+// Phase A:   out = bias + sum_s slab;  e = out - targ;  p = |e|^beta
+// kernerror, kernabsolutevalus, kernindex2 (DevFunc.cu:399-409,186-191,219-227 <- BP_GPU.cu:413-415).
+// Writes outT, eT, pT, all [Dp][Bp] with zeros in the pads.
 struct LossErrArgs {
     const float *slab;
     int S;
@@ -1211,41 +1219,26 @@ __device__ __forceinline__ void loss_err_body(const LossErrArgs &A, const int bi
     const float *__restrict__ slab = A.slab, *__restrict__ bias = A.bias, *__restrict__ targ = A.targ;
     float *__restrict__ outT = A.outT, *__restrict__ eT = A.eT, *__restrict__ pT = A.pT;
     const int *__restrict__ first = A.first;
-    const int S = A.S, B = A.B, D = A.D, Dp = A.Dp, Bp = A.Bp, want_pow = A.want_pow, b_tiles = A.b_tiles, toff = A.toff;
-    const float beta = A.beta;
     // first != nullptr: targ is the raw target frame stream and sample b's target is frame
     // first[b] + toff of it (Interface.cc:822-825); otherwise row b of the caller's [B][D] matrix
-    __shared__ float tt[32][33];
-    const int dt = bid / b_tiles, bt = bid % b_tiles;
-    const int d0 = dt * 32, b0 = bt * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int b = b0 + ty + 8 * q, d = d0 + tx;
-        tt[ty + 8 * q][tx] = (b < B && d < D) ? targ[(size_t)(first ? first[b] + toff : b) * D + d] : 0.0f;
+    const int dt = bid / A.b_tiles, bt = bid % A.b_tiles;
+    const int d = dt * LOSS_DT + (int)(threadIdx.x >> 5), b = bt * 32 + (int)(threadIdx.x & 31);
+    const size_t o = (size_t)d * A.Bp + b;
+    float x = slab_sum(slab, o, (size_t)A.Dp * A.Bp, A.S);
+    x = x + bias[d];
+    float e = 0.0f, p = 0.0f;
+    if (b < A.B && d < A.D) {
+        e = x - targ[(size_t)(first ? first[b] + A.toff : b) * A.D + d];  // kernerror
+        if (A.want_pow) p = powf(fabsf(e), A.beta);                       // kernabsolutevalus + kernindex2
+    } else {
+        x = 0.0f;
     }
-    __syncthreads();
-    const size_t slab_stride = (size_t)Dp * Bp;
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int dl = ty + 8 * q, d = d0 + dl, b = b0 + tx;
-        const size_t o = (size_t)d * Bp + b;
-        float x = slab_sum(slab, o, slab_stride, S);
-        x = x + bias[d];
-        float e = 0.0f, p = 0.0f;
-        if (b < B && d < D) {
-            e = x - tt[tx][dl];                       // kernerror
-            if (want_pow) p = powf(fabsf(e), beta);   // kernabsolutevalus + kernindex2
-        } else {
-            x = 0.0f;
-        }
-        outT[o] = x;
-        eT[o] = e;
-        pT[o] = p;
-    }
+    outT[o] = x;
+    eT[o] = e;
+    pT[o] = p;
 }
 // The blocks past n_loss stage the NEXT minibatch's input (it depends on nothing in this step and
-// Yt[0] is free once forward_1 has run): the loss kernel occupies 36 of 256 CUs, so the staging
+// Yt[0] is free once forward_1 has run): the loss workgroups occupy a fraction of the CUs, so the staging
 // blocks ride along on the idle ones instead of costing a launch of their own.
 __global__ __launch_bounds__(256) void k_loss_err(LossErrArgs A, int n_loss, StageArgs G) {
     const int n_stage = (int)gridDim.x - n_loss;  // staging blocks first: they are the longer ones
@@ -1255,17 +1248,18 @@ __global__ __launch_bounds__(256) void k_loss_err(LossErrArgs A, int n_loss, Sta
 
 // Per-dimension sum over the minibatch of |e|^beta in the reference's order (kernSumcol,
 // DevFunc.cu:167-185 <- BP_GPU.cu:416: one thread per column, rows added sequentially).
-// Shared by k_colsum (data-parallel path: the local sum is all-reduced) and k_loss_grad.
-// rows: LDS [32][Bp+1]; must be called by all 256 threads.
+// Shared by k_colsum (data-parallel path: the local sum is all-reduced; DT = 32) and k_loss_grad (DT = 8).
+// rows: LDS [DT][Bp+1]; must be called by all 256 threads.
+template <int DT>
 __device__ __forceinline__ void colsum_tile(const float *__restrict__ pT, int d0, int B, int Bp, float *rows,
                                             float *sums) {
-    const int total = 32 * Bp;
+    const int total = DT * Bp;
     for (int idx = threadIdx.x; idx < total; idx += 256) {
         const int dl = idx / Bp, b = idx - dl * Bp;
         rows[dl * (Bp + 1) + b] = pT[(size_t)(d0 + dl) * Bp + b];
     }
     __syncthreads();
-    if (threadIdx.x < 32) {
+    if (threadIdx.x < DT) {
         const float *col = rows + threadIdx.x * (Bp + 1);
         float s = col[0];  // kernSumcol: (*top) = (*fromp); then += in row order
         int b = 1;
@@ -1286,7 +1280,7 @@ __global__ __launch_bounds__(256) void k_colsum(const float *__restrict__ pT, in
                                                 float *__restrict__ colsum) {
     extern __shared__ __attribute__((aligned(16))) float dyn[];
     float *rows = dyn, *sums = dyn + 32 * (Bp + 1);
-    colsum_tile(pT, blockIdx.x * 32, B, Bp, rows, sums);
+    colsum_tile<32>(pT, blockIdx.x * 32, B, Bp, rows, sums);
     if (threadIdx.x < 32) colsum[blockIdx.x * 32 + threadIdx.x] = sums[threadIdx.x];
 }
 
@@ -1296,9 +1290,9 @@ __global__ __launch_bounds__(256) void k_colsum(const float *__restrict__ pT, in
 // MLflag == 1: alpha_d = (beta * colsum_d / n)^(1/beta) (kernDivide, kernVecMulNum,
 // kernindex2 <- BP_GPU.cu:417-420), g = sgn(e)|e|^(beta-1) * beta / alpha^beta / n
 // (kernfunc2 + kernVecMulNum, DevFunc.cu:468-489 <- BP_GPU.cu:422-423).
-// colsum_in == nullptr: the workgroup sums its 32 columns of pT itself (single GPU);
+// colsum_in == nullptr: the workgroup sums its 8 columns of pT itself (single GPU);
 // otherwise colsum_in is the GLOBAL minibatch sum (all-reduced).  nf = global minibatch size.
-// One workgroup per 32(d) x 32(b) tile; writes dEdXt and dEdX.  Dynamic LDS: 32*(Bp+1)+32 floats.
+// One workgroup per 8(d) x 32(b) tile; writes dEdXt and dEdX.  Dynamic LDS: 8*(Bp+1)+8 floats.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_loss_grad(const float *__restrict__ eT, const float *__restrict__ pT,
                                                    const float *__restrict__ colsum_in, int B, int D, int Dp, int Bp,
@@ -1306,20 +1300,19 @@ __global__ __launch_bounds__(256) void k_loss_grad(const float *__restrict__ eT,
                                                    float *__restrict__ scalefactor, float *__restrict__ dEdXt,
                                                    float *__restrict__ dEdX, int b_tiles) {
     extern __shared__ __attribute__((aligned(16))) float dyn[];
-    __shared__ float tileT[32][33];
-    __shared__ float denom[32];
+    __shared__ float denom[LOSS_DT];
     const int dt = blockIdx.x / b_tiles, bt = blockIdx.x % b_tiles;
-    const int d0 = dt * 32, b0 = bt * 32;
+    const int d0 = dt * LOSS_DT;
     const int tid = threadIdx.x;
     if (MLflag == 1) {
-        float *rows = dyn, *sums = dyn + 32 * (Bp + 1);
+        float *rows = dyn, *sums = dyn + LOSS_DT * (Bp + 1);
         if (colsum_in == nullptr) {
-            colsum_tile(pT, d0, B, Bp, rows, sums);
+            colsum_tile<LOSS_DT>(pT, d0, B, Bp, rows, sums);
         } else {
-            if (tid < 32) sums[tid] = colsum_in[d0 + tid];
+            if (tid < LOSS_DT) sums[tid] = colsum_in[d0 + tid];
             __syncthreads();
         }
-        if (tid < 32) {
+        if (tid < LOSS_DT) {
             const int d = d0 + tid;
             float q = 1.0f;
             if (d < D) {
@@ -1333,39 +1326,29 @@ __global__ __launch_bounds__(256) void k_loss_grad(const float *__restrict__ eT,
         }
         __syncthreads();
     }
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int el = tid + 256 * q, dl = el >> 5, bl = el & 31;
-        const int d = d0 + dl, b = b0 + bl;
-        const size_t o = (size_t)d * Bp + b;
-        const float e = eT[o];
-        float g = 0.0f;
-        if (b < B && d < D) {
-            if (MLflag == 1) {
-                if (e > 0) g = powf(e, beta - 1.0f) * beta / denom[dl];
-                else if (e == 0) g = 0;
-                else g = -powf(-e, beta - 1.0f) * beta / denom[dl];
-            } else {
-                if (e > 0) g = beta * powf(e, beta - 1);
-                else if (e == 0) g = 0;
-                else g = -beta * powf(-e, beta - 1);
-            }
-            g = g * inv_n;
+    const int dl = tid >> 5, d = d0 + dl, b = bt * 32 + (tid & 31);
+    const size_t o = (size_t)d * Bp + b;
+    const float e = eT[o];
+    float g = 0.0f;
+    if (b < B && d < D) {
+        if (MLflag == 1) {
+            if (e > 0) g = pow_or_self(e, beta - 1.0f) * beta / denom[dl];
+            else if (e == 0) g = 0;
+            else g = -pow_or_self(-e, beta - 1.0f) * beta / denom[dl];
+        } else {
+            if (e > 0) g = beta * pow_or_self(e, beta - 1);
+            else if (e == 0) g = 0;
+            else g = -beta * pow_or_self(-e, beta - 1);
         }
-        dEdXt[o] = g;
-        tileT[bl][dl] = g;
+        g = g * inv_n;
     }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int el = tid + 256 * q, bl = el >> 5, dl = el & 31;
-        dEdX[(size_t)(b0 + bl) * Dp + d0 + dl] = tileT[bl][dl];
-    }
+    dEdXt[o] = g;
+    dEdX[(size_t)b * Dp + d] = g;
 }
 
 // MLflag != 1 needs no statistic over the minibatch, so phases A and B collapse into one
 // elementwise pass: slab sum + bias -> error -> beta-norm gradient (same expressions and order as
-// k_loss_err / k_loss_grad), written as dEdXt and, through an LDS transpose, dEdX.
+// k_loss_err / k_loss_grad), written as dEdXt and dEdX.
 struct LossNormArgs {
     const float *slab;
     int S;
@@ -1381,47 +1364,26 @@ __device__ __forceinline__ void loss_norm_body(const LossNormArgs &A, const int 
     const float *__restrict__ slab = A.slab, *__restrict__ bias = A.bias, *__restrict__ targ = A.targ;
     float *__restrict__ outT = A.outT, *__restrict__ eT = A.eT, *__restrict__ dEdXt = A.dEdXt, *__restrict__ dEdX = A.dEdX;
     const int *__restrict__ first = A.first;
-    const int S = A.S, B = A.B, D = A.D, Dp = A.Dp, Bp = A.Bp, b_tiles = A.b_tiles, toff = A.toff;
-    const float beta = A.beta, inv_n = A.inv_n;
-    __shared__ float tt[32][33];
-    __shared__ float tg[32][33];
-    const int dt = bid / b_tiles, bt = bid % b_tiles;
-    const int d0 = dt * 32, b0 = bt * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int b = b0 + ty + 8 * q, d = d0 + tx;
-        tt[ty + 8 * q][tx] = (b < B && d < D) ? targ[(size_t)(first ? first[b] + toff : b) * D + d] : 0.0f;
+    const float beta = A.beta;
+    const int dt = bid / A.b_tiles, bt = bid % A.b_tiles;
+    const int d = dt * LOSS_DT + (int)(threadIdx.x >> 5), b = bt * 32 + (int)(threadIdx.x & 31);
+    const size_t o = (size_t)d * A.Bp + b;
+    float x = slab_sum(slab, o, (size_t)A.Dp * A.Bp, A.S);
+    x = x + bias[d];
+    float e = 0.0f, g = 0.0f;
+    if (b < A.B && d < A.D) {
+        e = x - targ[(size_t)(first ? first[b] + A.toff : b) * A.D + d];  // kernerror
+        if (e > 0) g = beta * pow_or_self(e, beta - 1);                    // kernSubClean2
+        else if (e == 0) g = 0;
+        else g = -beta * pow_or_self(-e, beta - 1);
+        g = g * A.inv_n;                                                   // kernVecMulNum
+    } else {
+        x = 0.0f;
     }
-    __syncthreads();
-    const size_t slab_stride = (size_t)Dp * Bp;
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int dl = ty + 8 * q, d = d0 + dl, b = b0 + tx;
-        const size_t o = (size_t)d * Bp + b;
-        float x = slab_sum(slab, o, slab_stride, S);
-        x = x + bias[d];
-        float e = 0.0f, g = 0.0f;
-        if (b < B && d < D) {
-            e = x - tt[tx][dl];  // kernerror
-            if (e > 0) g = beta * powf(e, beta - 1);  // kernSubClean2
-            else if (e == 0) g = 0;
-            else g = -beta * powf(-e, beta - 1);
-            g = g * inv_n;  // kernVecMulNum
-        } else {
-            x = 0.0f;
-        }
-        outT[o] = x;
-        eT[o] = e;
-        dEdXt[o] = g;
-        tg[tx][dl] = g;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int bl = ty + 8 * q;
-        dEdX[(size_t)(b0 + bl) * Dp + d0 + tx] = tg[bl][tx];
-    }
+    outT[o] = x;
+    eT[o] = e;
+    dEdXt[o] = g;
+    dEdX[(size_t)b * A.Dp + d] = g;
 }
 __global__ __launch_bounds__(256) void k_loss_norm(LossNormArgs A, int n_loss, StageArgs G) {
     const int n_stage = (int)gridDim.x - n_loss;  // staging blocks first: they are the longer ones
