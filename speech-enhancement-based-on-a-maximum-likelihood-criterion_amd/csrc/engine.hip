@@ -884,6 +884,18 @@ static int run_loss(mlggd_engine *e, const Bunch &bn, float nf, float inv_n, Col
         hipLaunchKernelGGL(k_loss_norm, dim3(n_loss + n_stage), dim3(256), 0, e->stream, la, n_loss, sa);
         return launch_check("k_loss_norm");
     }
+    if (ML == 1 && cs == CS_LOCAL && e->loss_fuse) {  // single device: the whole ML loss in one launch
+        LossMlArgs la;
+        la.slab = e->slab; la.S = e->S_out; la.bias = e->bias[L - 1]; la.targ = bn.targ;
+        la.B = B; la.D = e->D; la.Dp = e->Dp; la.Bp = Bp; la.beta = e->cfg.shapefactor; la.nf = nf; la.inv_n = inv_n;
+        la.outT = e->outT; la.eT = e->eT; la.scalefactor = e->scalefactor; la.dEdXt = e->dEdXt[L - 1]; la.dEdX = e->dEdX[L - 1];
+        la.first = bn.first; la.toff = e->toff;
+        const size_t lds_ml = (size_t)2 * LOSS_DT * (Bp + 1) * sizeof(float);
+        CHK(ensure_lds(e, k_loss_ml, (size_t)2 * LOSS_DT * (1152 + 1) * sizeof(float)));
+        hipLaunchKernelGGL(k_loss_ml, dim3(e->Dp / LOSS_DT + (n_stage + 3) / 4), dim3(1024), lds_ml, e->stream, la,
+                           e->Dp / LOSS_DT, sa, n_stage);
+        return launch_check("k_loss_ml");
+    }
     LossErrArgs la;
     la.slab = e->slab; la.S = e->S_out; la.bias = e->bias[L - 1]; la.targ = bn.targ;
     la.B = B; la.D = e->D; la.Dp = e->Dp; la.Bp = Bp; la.beta = e->cfg.shapefactor; la.want_pow = ML == 1 ? 1 : 0;

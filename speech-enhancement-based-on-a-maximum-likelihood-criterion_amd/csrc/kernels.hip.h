@@ -1145,31 +1145,41 @@ struct StageArgs {
     int fdim;
     float *rows_out;
 };
-__device__ __forceinline__ void transpose_in_body(const StageArgs &A, const int bid) {
+// SUB: 256-thread staging tiles per workgroup (1: the workgroup is one tile; 4: a 1024-thread workgroup stages tiles
+// 4*bid .. 4*bid+3, of which the ones past n_tiles do nothing but keep the barrier company)
+template <int SUB = 1>
+__device__ __forceinline__ void transpose_in_body(const StageArgs &A, const int bid, const int n_tiles = 0x7FFFFFFF) {
     const float *__restrict__ in = A.in;
     float *__restrict__ inT = A.inT, *__restrict__ rows_out = A.rows_out;
     const int *__restrict__ first = A.first;
     const int ld = A.ld, B = A.B, K = A.K, Bp = A.Bp, b_tiles = A.b_tiles, fdim = A.fdim;
-    __shared__ float t[32][33];
-    const int kt = bid / b_tiles, bt = bid % b_tiles;
+    __shared__ float ts[SUB][32][33];
+    const int sub = SUB == 1 ? 0 : (int)(threadIdx.x >> 8), tile = SUB * bid + sub;
+    float(*t)[33] = ts[sub];
+    const bool live = tile < n_tiles;
+    const int kt = tile / b_tiles, bt = tile % b_tiles;
     const int k0 = kt * 32, b0 = bt * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int tx = threadIdx.x & 31, ty = (threadIdx.x >> 5) & 7;
+    if (live) {
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int b = b0 + ty + 8 * q, k = k0 + tx;
-        float v = 0.0f;
-        if (b < B && k < K) {
-            const size_t base = first ? (size_t)first[b] * fdim : (size_t)b * ld;
-            v = in[base + k];
+        for (int q = 0; q < 4; q++) {
+            const int b = b0 + ty + 8 * q, k = k0 + tx;
+            float v = 0.0f;
+            if (b < B && k < K) {
+                const size_t base = first ? (size_t)first[b] * fdim : (size_t)b * ld;
+                v = in[base + k];
+            }
+            if (rows_out) rows_out[(size_t)b * A.Kp + k] = v;  // b < Bp, k < Kp: the grid's tiles cover exactly that
+            t[ty + 8 * q][tx] = v;
         }
-        if (rows_out) rows_out[(size_t)b * A.Kp + k] = v;  // b < Bp, k < Kp: the grid's tiles cover exactly that
-        t[ty + 8 * q][tx] = v;
     }
     __syncthreads();
+    if (live) {
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int k = k0 + ty + 8 * q;
-        inT[(size_t)k * Bp + b0 + tx] = t[tx][ty + 8 * q];
+        for (int q = 0; q < 4; q++) {
+            const int k = k0 + ty + 8 * q;
+            inT[(size_t)k * Bp + b0 + tx] = t[tx][ty + 8 * q];
+        }
     }
 }
 __global__ __launch_bounds__(256) void k_transpose_in(StageArgs A) { transpose_in_body(A, (int)blockIdx.x); }
@@ -1389,6 +1399,96 @@ __global__ __launch_bounds__(256) void k_loss_norm(LossNormArgs A, int n_loss, S
     const int n_stage = (int)gridDim.x - n_loss;  // staging blocks first: they are the longer ones
     if ((int)blockIdx.x >= n_stage) loss_norm_body(A, (int)blockIdx.x - n_stage);
     else transpose_in_body(G, (int)blockIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------
+// The whole ML-GGD loss (BP_GPU.cu:413-423: kernerror, kernabsolutevalus, kernindex2, kernSumcol, kernDivide,
+// kernVecMulNum, kernindex2, kernfunc2, kernVecMulNum) in ONE launch on a single device: a workgroup of 1024
+// threads owns 8 output units over ALL frames of the minibatch, so the per-dimension statistic never leaves its
+// LDS: e and p = |e|^beta for its 8 x Bp elements (one per thread at B = 128), the 8 column sums in the reference's
+// sequential order (8 threads, as kernSumcol), alpha and alpha^beta, then the gradient of the same elements.
+// Replaces k_loss_err + k_loss_grad and the pT / eT round trip between them (ML step -3.5 us); the data-parallel
+// path keeps the two-kernel form because the statistic has to be summed over the ranks in between.
+// Dynamic LDS: 2 * 8 * (Bp + 1) floats.  The staging blocks of the next minibatch ride along as in k_loss_norm,
+// four 256-thread tiles per 1024-thread workgroup.
+// ---------------------------------------------------------------------------------------
+struct LossMlArgs {
+    const float *slab;
+    int S;
+    const float *bias, *targ;
+    int B, D, Dp, Bp;
+    float beta, nf, inv_n;
+    float *outT, *eT, *scalefactor, *dEdXt, *dEdX;
+    const int *first;
+    int toff;
+};
+__global__ __launch_bounds__(1024) void k_loss_ml(LossMlArgs A, int n_loss, StageArgs G, int n_stage_tiles) {
+    const int n_stage = (int)gridDim.x - n_loss;
+    if ((int)blockIdx.x < n_stage) {
+        transpose_in_body<4>(G, (int)blockIdx.x, n_stage_tiles);
+        return;
+    }
+    extern __shared__ __attribute__((aligned(16))) float dyn[];
+    __shared__ float denom[LOSS_DT];
+    const float *__restrict__ slab = A.slab, *__restrict__ bias = A.bias, *__restrict__ targ = A.targ;
+    const int *__restrict__ first = A.first;
+    const int B = A.B, D = A.D, Dp = A.Dp, Bp = A.Bp;
+    const float beta = A.beta;
+    float *es = dyn, *ps = dyn + LOSS_DT * (Bp + 1);  // [8][Bp+1] each
+    const int d0 = ((int)blockIdx.x - n_stage) * LOSS_DT;
+    const int tid = threadIdx.x, dl = tid >> 7, d = d0 + dl;  // 8 units x 128 frames per pass
+    for (int b = tid & 127; b < Bp; b += 128) {
+        const size_t o = (size_t)d * Bp + b;
+        float x = slab_sum(slab, o, (size_t)Dp * Bp, A.S);
+        x = x + bias[d];
+        float e = 0.0f, p = 0.0f;
+        if (b < B && d < D) {
+            e = x - targ[(size_t)(first ? first[b] + A.toff : b) * D + d];  // kernerror
+            p = powf(fabsf(e), beta);                                       // kernabsolutevalus + kernindex2
+        } else {
+            x = 0.0f;
+        }
+        A.outT[o] = x;
+        A.eT[o] = e;
+        es[dl * (Bp + 1) + b] = e;
+        ps[dl * (Bp + 1) + b] = p;
+    }
+    __syncthreads();
+    if (tid < LOSS_DT) {
+        const float *col = ps + tid * (Bp + 1);
+        float s = col[0];  // kernSumcol: (*top) = (*fromp); then += in row order
+        int b = 1;
+        for (; b + 16 <= B; b += 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) v[u] = col[b + u];
+#pragma unroll
+            for (int u = 0; u < 16; u++) s += v[u];
+        }
+        for (; b < B; b++) s += col[b];
+        float q = 1.0f;
+        if (d0 + tid < D) {
+            const float v1 = s / A.nf;                  // kernDivide
+            const float v2 = v1 * beta;                 // kernVecMulNum
+            const float alpha = powf(v2, 1.0f / beta);  // kernindex2 with ppp = 1.0f/shapefactor
+            A.scalefactor[d0 + tid] = alpha;
+            q = powf(alpha, beta);                      // pow(vec[j], alpha) in kernfunc2
+        }
+        denom[tid] = q;
+    }
+    __syncthreads();
+    for (int b = tid & 127; b < Bp; b += 128) {
+        const float e = es[dl * (Bp + 1) + b];
+        float g = 0.0f;
+        if (b < B && d < D) {
+            if (e > 0) g = pow_or_self(e, beta - 1.0f) * beta / denom[dl];  // kernfunc2
+            else if (e == 0) g = 0;
+            else g = -pow_or_self(-e, beta - 1.0f) * beta / denom[dl];
+            g = g * A.inv_n;                                                  // kernVecMulNum
+        }
+        A.dEdXt[(size_t)d * Bp + b] = g;
+        A.dEdX[(size_t)b * Dp + d] = g;
+    }
 }
 
 // Forward-only output (cv_bunch_single, BP_GPU.cu:442-512): out[b][d] = bias + sum_s slab,
