@@ -131,7 +131,9 @@ int mlggd_set_lrate(mlggd_handle h, float lrate);
 /* CV metrics: on = the three sums are formed on the device (per-tile partials in double, combined
  * on the host; no n x D copy, no host loop); off (default, or env MLGGD_CV_DEVICE=0) = outputs copied back and
  * accumulated on the host in fp32 in the reference's frame-major order (BP_GPU.cu:207-213), the values the
- * reference's log lines carry.  The two differ by the rounding of that fp32 accumulation (~1e-5 relative). */
+ * reference's log lines carry.  The two differ by the rounding of that fp32 accumulation, which grows with the size
+ * of the CV set: 1e-5 relative at 1,200 frames, 1.4e-3 at 7,920 frames x 257 (the running sum is then ~1e7 times a
+ * term); the device sums are the accurate ones, the host-order ones are what the reference prints. */
 int mlggd_set_cv_device_reduce(mlggd_handle h, int on);
 float mlggd_gamma(float x); /* BP_GPU::Gamma, BP_GPU.cu:593-640 */
 

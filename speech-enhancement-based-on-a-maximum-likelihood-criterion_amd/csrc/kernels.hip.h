@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
@@ -143,6 +144,19 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &A, const int bid, float 
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[r] = 0.0f;
 
+    // The epilogue's global operands (the bias of this thread's output elements) are fetched NOW: left alone the
+    // compiler sinks the loads behind the last barrier, one after the other, and their L2 latency -- twice -- is the
+    // tail of every launch (round 2: the ISA showed load -> exp -> store -> load -> exp -> store after the
+    // reduction).  The empty asm with a "memory" clobber is a compiler-level fence the loads cannot be sunk across;
+    // it does not use their values, so nothing waits for them until the epilogue does.  (A/B in one process: dX -0.2 ..
+    // -0.3 us per launch, forward within noise: the loads hit L2.)
+    constexpr int NT_ = 64 * NW, EPT_ = 1024 / NT_ > 0 ? 1024 / NT_ : 1;
+    static_assert(1024 % NT_ == 0, "every thread owns EPT_ whole output elements");
+    float bias_pre[EPT_];
+#pragma unroll
+    for (int q = 0; q < EPT_; q++) bias_pre[q] = MODE == FWD_SIGMOID ? bias[n0 + ((tid + NT_ * q) >> 5)] : 0.0f;
+    asm volatile("" ::: "memory");
+
     float4 wa[4], ya[4], wb[4], yb[4];
     // rows past Kp are range-checked zeros; rows past this wave's range are only ever
     // multiplied under the npairs guard of the drain
@@ -226,7 +240,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &A, const int bid, float 
             const int e = tid + NT * q, row = e >> 5, col = e & 31;
             if (e < 1024) {
                 const int n = n0 + row;
-                const float x = v[q] + bias[n];
+                const float x = v[q] + bias_pre[q];
                 const float y = (n < N) ? 1.0f / (1.0f + expf(-x)) : 0.0f;  // kernSigmoid, DevFunc.cu:48
                 Yt_out[(size_t)n * Bp + b0 + col] = y;
                 tileT[col][row] = y;
@@ -309,6 +323,18 @@ __device__ __forceinline__ void dx_body(const DxArgs &A, const int bid, float *s
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[r] = 0.0f;
 
+    // the epilogue's global operand (y of this thread's output elements, for the sigmoid derivative) is fetched now,
+    // above a compiler-level fence, not behind the last barrier (see fwd_body)
+    constexpr int NT_ = 64 * NW, EPT_ = 1024 / NT_ > 0 ? 1024 / NT_ : 1;
+    static_assert(1024 % NT_ == 0, "every thread owns EPT_ whole output elements");
+    float y_pre[EPT_];
+#pragma unroll
+    for (int q = 0; q < EPT_; q++) {
+        const int e_ = tid + NT_ * q;
+        y_pre[q] = Yt_prev[(size_t)(k0 + (e_ >> 5)) * Bp + b0 + (e_ & 31)];
+    }
+    asm volatile("" ::: "memory");
+
     float4 wa[8], da[8], wv[8], dv[8];
     // Quads past this wave's range read valid or range-checked-zero data and are only ever
     // multiplied under the count guard of the drain.
@@ -380,7 +406,7 @@ __device__ __forceinline__ void dx_body(const DxArgs &A, const int bid, float *s
 #pragma unroll
             for (int w = 1; w < NW; w++) dedy += red[w][e];
             const size_t o = (size_t)(k0 + row) * Bp + b0 + col;
-            const float y = Yt_prev[o];
+            const float y = y_pre[q];
             const float g = (1.0f - y) * y * dedy;  // kernDsigmoid, DevFunc.cu:67-68
             dEdXt_prev[o] = g;
             tileT[col][row] = g;
@@ -750,6 +776,8 @@ __device__ __forceinline__ void dwp_body(const DwpDesc *__restrict__ table, cons
 #define DWP_NBIAS(T) ((int)(((T).packed >> 16) & 0xFFu))
 #define DWP_SZAB(T) ((((T).packed >> 24) & 1u) ? 0x7FFFFFFFu : 0u) /* operand reads never leave the allocation */
 #define DWP_DIVN(x) (POW2 ? (x) * inv_nf : (x) / nf)
+#define DWP_DIVN2(x) (POW2 ? (x) * inv2 : (x) / nf2)
+    const f32x2 mom2 = {mom, mom}, lr2 = {lr, lr}, wc2 = {wc, wc}, inv2 = {inv_nf, inv_nf}, nf2 = {nf, nf}, one2 = {1.0f, 1.0f};
     // voffset of this lane's float4 number IT of the wave tile of T; OOB for rows / columns that do not exist
 #define DWP_OFF(T, IT)                                                                          \
     (((32 * wm + er + 8 * (IT)) < DWP_ROWS(T) && (32 * wn + 4 * ec) < DWP_COLS(T))               \
@@ -819,21 +847,33 @@ __device__ __forceinline__ void dwp_body(const DwpDesc *__restrict__ table, cons
         gq[IT] = *reinterpret_cast<const float4 *>(lds + (SB)*8192 + wave * 256 + (IT)*1024 + (er >> 1) * 64 + (er & 1) * 32 + 4 * ec); \
         asm volatile("" : "+v"(gq[IT].x), "+v"(gq[IT].y), "+v"(gq[IT].z), "+v"(gq[IT].w));     \
     }
+    // two weights per instruction (v_pk_mul_f32 / v_pk_add_f32: IEEE multiply / add per element, no contraction, so
+    // the bits are those of the scalar expression): the fp32 MFMA occupies the SIMD's fp32 lanes, VALU work does
+    // not hide behind it, and this halves the update's instruction count
 #define DWP_EPI_UPDATE(PW, PD, IT)                                                              \
     {                                                                                           \
-        const float4 gv_ = gq[IT];                                                                \
+        const float4 gv_ = gq[IT];                                                              \
         const int off = DWP_OFF(tp, IT);                                                        \
-        if (FUSED) { /* kernUpdatedelta (DevFunc.cu:502) then kernAccSum (DevFunc.cu:440) */    \
+        if (FUSED && (ABL & 256)) { /* scalar form of the same expressions (A/B only) */        \
             const float4 w = PW[IT];                                                            \
             float4 d = PD[IT];                                                                  \
-            d.x = mom * d.x - lr * (DWP_DIVN(gv_.x) + wc * w.x);                                  \
-            d.y = mom * d.y - lr * (DWP_DIVN(gv_.y) + wc * w.y);                                  \
-            d.z = mom * d.z - lr * (DWP_DIVN(gv_.z) + wc * w.z);                                  \
-            d.w = mom * d.w - lr * (DWP_DIVN(gv_.w) + wc * w.w);                                  \
+            d.x = mom * d.x - lr * (DWP_DIVN(gv_.x) + wc * w.x);                                \
+            d.y = mom * d.y - lr * (DWP_DIVN(gv_.y) + wc * w.y);                                \
+            d.z = mom * d.z - lr * (DWP_DIVN(gv_.z) + wc * w.z);                                \
+            d.w = mom * d.w - lr * (DWP_DIVN(gv_.w) + wc * w.w);                                \
             bstore4(d, rDp, off);                                                               \
             bstore4(make_float4(d.x + 1.0f * w.x, d.y + 1.0f * w.y, d.z + 1.0f * w.z, d.w + 1.0f * w.w), rWp, off); \
+        } else if (FUSED) { /* kernUpdatedelta (DevFunc.cu:502) then kernAccSum (DevFunc.cu:440) */ \
+            const f32x2 w0 = {PW[IT].x, PW[IT].y}, w1 = {PW[IT].z, PW[IT].w};                   \
+            f32x2 d0 = {PD[IT].x, PD[IT].y}, d1 = {PD[IT].z, PD[IT].w};                         \
+            const f32x2 g0 = {gv_.x, gv_.y}, g1 = {gv_.z, gv_.w};                               \
+            d0 = mom2 * d0 - lr2 * (DWP_DIVN2(g0) + wc2 * w0);                                  \
+            d1 = mom2 * d1 - lr2 * (DWP_DIVN2(g1) + wc2 * w1);                                  \
+            const f32x2 n0 = d0 + one2 * w0, n1 = d1 + one2 * w1;                               \
+            bstore4(make_float4(d0.x, d0.y, d1.x, d1.y), rDp, off);                             \
+            bstore4(make_float4(n0.x, n0.y, n1.x, n1.y), rWp, off);                             \
         } else {                                                                                \
-            bstore4(gv_, rWp, off);                                                               \
+            bstore4(gv_, rWp, off);                                                             \
         }                                                                                       \
     }
     long long ph_sum[5] = {0, 0, 0, 0, 0}, ph_last = 0;
@@ -1015,6 +1055,7 @@ __device__ __forceinline__ void dwp_body(const DwpDesc *__restrict__ table, cons
 #undef DWP_NBIAS
 #undef DWP_SZAB
 #undef DWP_DIVN
+#undef DWP_DIVN2
 }
 
 // ---------------------------------------------------------------------------------------

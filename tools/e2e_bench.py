@@ -20,7 +20,8 @@ subprocess.check_call([os.path.join(hostlib.HOST, "gen_rand_net"), "5", *map(str
 exe = os.path.join(hostlib.HOST, "BPtrain_Sigmoid")
 ntrain = nsent - 8
 samples = ntrain * (slen - ctx + 1)
-for mode, env in (("frame-stream (device gather)", {}), ("host expansion (reference style)", {"MLGGD_EXPANDED": "1"})):
+for mode, env in (("frame-stream (device gather)", {}), ("frame-stream, CV sums on the device", {"MLGGD_CV_DEVICE": "1"}),
+                  ("host expansion (reference style)", {"MLGGD_EXPANDED": "1"})):
     kv = dict(gpu_used=0, numlayers=5, layersizes=",".join(map(str, ls)), bunchsize=128, MLflag=1, shapefactor=1.2,
               momentum=0.9, weightcost=1e-5, lrate=0.1, fea_dim=dim, fea_context=ctx, traincache=102400,
               init_randem_seed=27870775, targ_offset=5, initwts_file=d + "/init.wts", norm_file=d + "/n.norm",
