@@ -164,8 +164,9 @@ def main():
             gbps = by / (us * 1e-6) / 1e9
             mode = eng.dp_mode() if world > 1 else 0  # 2, 3: the fused kernel runs over the gathered minibatch
             units = max(1, ((B + 31) // 32 * 32) * (world if mode >= 2 else 1) // 64)
-            name = "k_dwp<%d,%s> (persistent dW GEMM + fused momentum/weight-decay/bias update, %s%s)" % (
-                units, "true" if mode != 1 else "false",
+            n_glob = B * world
+            name = "k_dwp<%d,%s,%s> (persistent dW GEMM + fused momentum/weight-decay/bias update, %s%s)" % (
+                units, "true" if mode != 1 else "false", "true" if n_glob & (n_glob - 1) == 0 else "false",
                 "all layers in one launch" if nl == 1 else "one launch per layer",
                 {0: "", 1: "", 2: ", over the %d gathered frames of all ranks" % (B * world),
                  3: ", this rank's block of weight rows over the %d gathered frames of all ranks" % (B * world)}[mode])

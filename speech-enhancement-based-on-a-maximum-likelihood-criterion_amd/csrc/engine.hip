@@ -778,6 +778,8 @@ static int shard_alloc(mlggd_engine *e) {
             HIPCHK(hipMemcpyAsync(nw, e->W[l], (size_t)Kp * Np * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
             HIPCHK(hipStreamSynchronize(e->stream));
             e->W[l] = nw;  // the old buffer stays on the free list
+            for (auto &t : e->dwp_tables) hipFree(t.dev);  // tile records built so far point into the old buffer
+            e->dwp_tables.clear();
         }
         HIPCHK(hipEventCreateWithFlags(&e->ev_W[l], hipEventDisableTiming));
     }
