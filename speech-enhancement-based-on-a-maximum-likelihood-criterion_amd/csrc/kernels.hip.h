@@ -734,7 +734,8 @@ struct DwpConst {
 // unit, [3] unused, [4] the last hand-off, over all its tiles -> row nblocks + bid of the stamp buffer.
 // ABL: timing-only ablations of the diagnostic twins (wrong results by construction; MLGGD_DWP_ABLATE):
 // 1 no epilogue update / stores, 2 no W / delta loads, 4 no MFMAs, 8 no fragment reads and no MFMAs, 16 no operand
-// loads, 32 no operand LDS writes.
+// loads, 32 no operand LDS writes; and two A/B switches with correct results: 64 operand LDS writes after the block
+// instead of inside it, 256 the update in scalar instead of packed fp32 instructions.
 template <int H, bool FUSED, bool POW2, bool PHASES = false, int ABL = 0>
 __device__ __forceinline__ void dwp_body(const DwpDesc *__restrict__ table, const int total, const DwpConst C, const int bid,
                                          const int nblocks, float *lds, long long *stamps) {
@@ -928,8 +929,8 @@ __device__ __forceinline__ void dwp_body(const DwpDesc *__restrict__ table, cons
             /* operands of the next unit: one 16-byte load per group -- two per group in the unit that carries the     \
                pending epilogue, so that all of them are OLDER than its stores (groups 4..10): s_waitcnt vmcnt counts  \
                in issue order, and the hand-off below must not have to wait for a store to be acknowledged */          \
-            if (!(ABL & 16) && ((FIRSTU || (ABL & 128)) ? g < 4 : g < 8)) {                      \
-                const bool two_ = FIRSTU || (ABL & 128);                                        \
+            if (!(ABL & 16) && (FIRSTU ? g < 4 : g < 8)) {                                       \
+                const bool two_ = FIRSTU;                                                       \
                 const int q = two_ ? g : g >> 1, row = row0_ + srow + 16 * q;                    \
                 if (two_ || (g & 1) == 0) ra[q] = bload4(rA_, (row * ldA_ + 4 * scol) * 4, 0);   \
                 if (two_ || (g & 1) == 1) rb[q] = bload4(rB_, (row * ldB_ + 4 * scol) * 4, 0);   \

@@ -26,7 +26,6 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
 res = {}
 names[64] = "operand LDS writes after the last MFMA instead of inside the block (correct results)"
 names[256] = "update in scalar fp32 instructions instead of packed pairs (correct results)"
-names[128] = "EXPERIMENT: operand loads two per group in groups 0..3 in every unit (correct results)"
 variants = [int(x) for x in sys.argv[1:]] or [0, 1, 2, 3, 4, 16, 48, 7, 15, 31, 63]
 for rnd in range(3 if len(variants) <= 3 else 2):
     for abl in variants:
