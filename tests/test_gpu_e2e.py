@@ -168,12 +168,14 @@ def test_frame_stream_chunks_equal_expanded_chunks_bitwise(pkg, synth, ml, beta)
     b.close()
 
 
+@pytest.mark.parametrize("ml,beta", [(0, 2.0), (1, 1.2)])
 @pytest.mark.parametrize("frames_mode", [False, True])
-def test_launch_plan_knobs_do_not_change_a_bit(pkg, synth, monkeypatch, frames_mode):
+def test_launch_plan_knobs_do_not_change_a_bit(pkg, synth, monkeypatch, frames_mode, ml, beta):
     """The launch-plan optimisations (next minibatch staged alongside the loss kernel, one dW launch
-    for all layers, fused MMSE loss kernel) reorder launches, not arithmetic: weights after 5 steps are
-    bit-identical with each of them switched off, for expanded and for frame-stream chunks, and when
-    the chunk is trained in two calls (the staged-ahead bunch is then dropped at the call boundary)."""
+    for all layers, the loss in one launch -- k_loss_norm for MMSE, k_loss_ml for ML-GGD) reorder launches, not
+    arithmetic: weights after 5 steps are bit-identical with each of them switched off, for expanded and for
+    frame-stream chunks, and when the chunk is trained in two calls (the staged-ahead bunch is then dropped at the
+    call boundary)."""
     dim, ctx, B, toff = 40, 5, 64, 2
     ls = [dim * ctx, 96, 70, dim]
     rng = np.random.default_rng(5)
@@ -191,7 +193,7 @@ def test_launch_plan_knobs_do_not_change_a_bit(pkg, synth, monkeypatch, frames_m
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
-        eng = pkg.BPGpu(1, 0, ls, B, *HP, ws, bs, 2.0, 0)
+        eng = pkg.BPGpu(1, 0, ls, B, *HP, ws, bs, beta, ml)
         if frames_mode:
             eng.load_frames(feat, targ, first, ctx, toff)
         else:
