@@ -12,6 +12,9 @@ up to 5 ranks and sharded from 6; MLGGD_DP_MODE=allredu
 the weight gradients); torch.distributed is only used for the rendezvous, the barriers and the max-over-ranks
 of the wall time.
 
+`loss_vs_oracle` (and `ml_ggd.loss_vs_oracle`) is BASELINE.json's "loss-vs-ref delta": relative difference of the CV
+numbers the reference logs (BPtrain.cc:131-138) between this engine and the CPU oracle after the same steps.
+
 The timed region contains nothing but the K steps.  The `roofline` object comes from an UNTIMED post-pass of
 64 further steps in which every launch of the dominant kernel carries a HIP start/stop event pair on the engine's
 stream (hipExtLaunchKernelGGL: the dispatch's own begin/end timestamps, comparable with rocprofv3's average); `ml_ggd` is BASELINE.json configs[2] (MLflag=1, beta=1.2) measured the same way in the same invocation.
@@ -234,7 +237,43 @@ def main():
         out["cpu_baseline"] = {"value": round(n * B / cdt, 1), "unit": "frames/s", "cores": pyoracle.num_threads(),
                                "kind": "port", "sample": "%d steps over the same %d-frame minibatches (oracle, OpenMP, threads = usable CPU share)"
                                % (n, B), "gpu_over_cpu": round(value / (n * B / cdt), 1)}
+
+        # BASELINE.json's "loss-vs-ref delta": a fresh engine trains exactly the steps the oracle has just been timed
+        # on (the oracle here is the CHECKER; nothing below is timed), then both score a held-out synthetic chunk with
+        # the numbers the reference logs after an epoch (BPtrain.cc:131-138).  configs[2] (ML-GGD) gets a shorter run.
+        def loss_delta(ml_, beta_, ora_, n_):
+            chk = pkg.BPGpu(synth.DEFAULT_SEED, local_rank, ls, B, 0.1, 0.9, 1e-5, ws, bs, beta_, ml_)
+            chk.train(inp[:B], targ[:B])
+            chk.train(inp[:B], targ[:B])
+            chk.load_chunk(inp, targ)
+            done = 0
+            while done < n_:
+                m = min(n_ - done, nb)
+                chk.train_resident(0, m * B)
+                done += m
+            cin, ctarg = synth.make_frames(1000, 257, 11, seed=77)
+            sq, ab, ll = chk.cv_all(cin, ctarg)
+            osq, oab = ora_.cv_sqerr(cin, ctarg), ora_.cv_abserr(cin, ctarg)
+            d = {"steps": n_ + 2, "cv_sqerr_rel": abs(sq - osq) / abs(osq), "cv_abserr_rel": abs(ab - oab) / abs(oab)}
+            if ml_:
+                oll = ora_.cv_loglik(cin, ctarg)
+                alpha, oalpha = chk.scalefactor(), ora_.tensor("scalefactor")
+                d["cv_loglik_rel"] = abs(ll - oll) / abs(oll)
+                d["alpha_relmax"] = float(np.abs(alpha - oalpha).max() / np.abs(oalpha).max())
+            chk.close()
+            return {k: (v if k == "steps" else float("%.2e" % v)) for k, v in d.items()}
+
+        out["loss_vs_oracle"] = loss_delta(ml, beta, ora, n)
         ora.close()
+        if "ml_ggd" in out:
+            n_ml = min(n, 150)
+            ora = pyoracle.OracleNet(ls, B, 0.1, 0.9, 1e-5, 1.2, 1, ws, bs)
+            ora.train_bunch(inp[:B], targ[:B])
+            ora.train_bunch(inp[:B], targ[:B])
+            for i in range(n_ml):
+                ora.train_bunch(inp[(i % nb) * B:(i % nb + 1) * B], targ[(i % nb) * B:(i % nb + 1) * B])
+            out["ml_ggd"]["loss_vs_oracle"] = loss_delta(1, 1.2, ora, n_ml)
+            ora.close()
     eng.close()
     if world > 1:
         dist.barrier()
