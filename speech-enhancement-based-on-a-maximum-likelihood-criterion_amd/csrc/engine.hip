@@ -672,7 +672,7 @@ static int launch_dwp_t(mlggd_engine *e, const DwpJobs &J, bool fused, hipStream
         launch_timed(e, k_dwp_ablate<H, A_>, dim3(grid), dim3(256), lds, st, table, J.total, C, stamps);  \
         return launch_check("k_dwp_ablate");
             switch (abl) {
-                DWP_ABL(1) DWP_ABL(2) DWP_ABL(3) DWP_ABL(4) DWP_ABL(7) DWP_ABL(15) DWP_ABL(31) DWP_ABL(63) DWP_ABL(16) DWP_ABL(48) DWP_ABL(64) DWP_ABL(256)
+                DWP_ABL(1) DWP_ABL(2) DWP_ABL(3) DWP_ABL(4) DWP_ABL(7) DWP_ABL(15) DWP_ABL(31) DWP_ABL(63) DWP_ABL(16) DWP_ABL(48) DWP_ABL(256) DWP_ABL(512) DWP_ABL(576)
             default: return fail(MLGGD_ERR_ARG, "MLGGD_DWP_ABLATE=%d is not built", abl);
             }
 #undef DWP_ABL

@@ -841,12 +841,13 @@ __device__ __forceinline__ void dwp_body(const DwpDesc *__restrict__ table, cons
             Tw[(kl >> 3) * 1024 + ((kl >> 1) & 3) * 64 + (kl & 1) * 32 + i] = accp[r];          \
         }                                                                                       \
     }
-    // (the empty asm pins the read to the group it is written in: left alone, the compiler sinks the LDS load down
-    // to its first use two groups later and then waits for it with lgkmcnt(0) in front of an MFMA)
+    // (the empty asm with a "memory" clobber is a compiler-level fence that pins the read to the group it is written
+    // in: left alone, the compiler sinks the LDS load down to its first use two groups later and then waits for it
+    // with lgkmcnt(0) in front of an MFMA; the fence does not USE the value, so nothing waits for it here either)
 #define DWP_EPI_SCRATCH_READ(SB, IT)                                                            \
     {                                                                                           \
         gq[IT] = *reinterpret_cast<const float4 *>(lds + (SB)*8192 + wave * 256 + (IT)*1024 + (er >> 1) * 64 + (er & 1) * 32 + 4 * ec); \
-        asm volatile("" : "+v"(gq[IT].x), "+v"(gq[IT].y), "+v"(gq[IT].z), "+v"(gq[IT].w));     \
+        asm volatile("" ::: "memory");                                                          \
     }
     // two weights per instruction (v_pk_mul_f32 / v_pk_add_f32: IEEE multiply / add per element, no contraction, so
     // the bits are those of the scalar expression): the fp32 MFMA occupies the SIMD's fp32 lanes, VALU work does
@@ -929,7 +930,26 @@ __device__ __forceinline__ void dwp_body(const DwpDesc *__restrict__ table, cons
             /* operands of the next unit: one 16-byte load per group -- two per group in the unit that carries the     \
                pending epilogue, so that all of them are OLDER than its stores (groups 4..10): s_waitcnt vmcnt counts  \
                in issue order, and the hand-off below must not have to wait for a store to be acknowledged */          \
-            if (!(ABL & 16) && (FIRSTU ? g < 4 : g < 8)) {                                       \
+            /* operands of the next unit straight into LDS by LDS-DMA (buffer_load ... lds): no staging registers  \
+               (-28 VGPRs), no ds_write_b128, -2.4 % launch time (ABL & 512 restores the register path for A/B).   \
+               Wave w's 64 lanes fill rows 4w..4w+3 (+16q) of the A / B halves, 1 KB contiguous per instruction,   \
+               which is exactly the row-major layout the fragment reads expect.  In the unit that carries a         \
+               pending epilogue the A rows are its scratch, so they are filled only after the scratch has been      \
+               read back (groups 6..9); the B rows go first (groups 0..3). */                    \
+            if (!(ABL & 512) && !(ABL & 16)) {                                                  \
+                const int qa = FIRSTU ? g - 6 : g, qb = FIRSTU ? g : g - 4;                     \
+                if (qa >= 0 && qa < 4) {                                                        \
+                    float *dst = lds + ((BUF) ^ 1) * 8192 + (4 * wave + 16 * qa) * 64;          \
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rA_, (__attribute__((address_space(3))) void *)dst, 16, \
+                                                             ((row0_ + srow + 16 * qa) * ldA_ + 4 * scol) * 4, 0, 0, 0); \
+                }                                                                               \
+                if (qb >= 0 && qb < 4) {                                                        \
+                    float *dst = lds + ((BUF) ^ 1) * 8192 + 4096 + (4 * wave + 16 * qb) * 64;   \
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rB_, (__attribute__((address_space(3))) void *)dst, 16, \
+                                                             ((row0_ + srow + 16 * qb) * ldB_ + 4 * scol) * 4, 0, 0, 0); \
+                }                                                                               \
+            }                                                                                   \
+            if ((ABL & 512) && !(ABL & 16) && (FIRSTU ? g < 4 : g < 8)) {                        \
                 const bool two_ = FIRSTU;                                                       \
                 const int q = two_ ? g : g >> 1, row = row0_ + srow + 16 * q;                    \
                 if (two_ || (g & 1) == 0) ra[q] = bload4(rA_, (row * ldA_ + 4 * scol) * 4, 0);   \
@@ -960,10 +980,10 @@ __device__ __forceinline__ void dwp_body(const DwpDesc *__restrict__ table, cons
                     else PD[g - 12] = bload4(rDn, DWP_OFF(tn, g - 12), 0);                      \
                 }                                                                               \
             }                                                                                   \
-            /* the next unit's operands go to LDS inside the block too (groups 12..15: their loads are 8+ groups old; \
-               the scratch of a pending epilogue in the same rows was read back in groups 2..5): after the block only \
-               the barrier is left (-3 % launch time against writing them after the last MFMA; ABL & 64 restores that) */ \
-            if (!(ABL & (32 | 64)) && g >= 12) {                                                \
+            /* register path only (ABL & 512): the next unit's operands go to LDS inside the block (groups 12..15:  \
+               their loads are 8+ groups old; the scratch of a pending epilogue in the same rows was read back in     \
+               groups 2..5), -3 % launch time against writing them after the last MFMA (ABL & 64) */ \
+            if ((ABL & 512) && !(ABL & (32 | 64)) && g >= 12) {                                 \
                 float *as_ = lds + ((BUF) ^ 1) * 8192, *bs_ = as_ + 4096;                       \
                 *reinterpret_cast<float4 *>(as_ + (srow + 16 * (g - 12)) * 64 + 4 * scol) = ra[g - 12]; \
                 *reinterpret_cast<float4 *>(bs_ + (srow + 16 * (g - 12)) * 64 + 4 * scol) = rb[g - 12]; \
@@ -972,6 +992,20 @@ __device__ __forceinline__ void dwp_body(const DwpDesc *__restrict__ table, cons
         }                                                                                       \
         DWP_PHASE(LASTU ? 2 : 0)                                                                \
         if ((ABL & 64) && !(ABL & 32)) DWP_WRITE_UNIT((BUF) ^ 1)                                \
+        if (!(ABL & 512)) {                                                                     \
+            /* every wave's own DMA has to have landed before the barrier lets the others read its rows: wait for   \
+               all vector-memory operations but the ones issued after the last DMA of this unit (vmcnt counts in     \
+               issue order): first unit: 2 stores of group 10 (+ 8 W / delta loads of groups 12..15 when it is also \
+               the last); other last units: 8 W / delta loads; otherwise none */                 \
+            constexpr int lo_ = 0;                                                              \
+            const int younger = FIRSTU ? ((FUSED ? 2 : 1) + ((LASTU && FUSED) ? 8 : 0)) : ((LASTU && FUSED) ? 8 : 0); \
+            if (younger == 0) __builtin_amdgcn_s_waitcnt(0x0F70 | lo_);                         \
+            else if (younger == 1) __builtin_amdgcn_s_waitcnt(0x0F71);                          \
+            else if (younger == 2) __builtin_amdgcn_s_waitcnt(0x0F72);                          \
+            else if (younger == 8) __builtin_amdgcn_s_waitcnt(0x0F78);                          \
+            else if (younger == 9) __builtin_amdgcn_s_waitcnt(0x0F79);                          \
+            else __builtin_amdgcn_s_waitcnt(0x0F7A);                                            \
+        }                                                                                       \
         __syncthreads();                                                                        \
         DWP_PHASE(LASTU ? 4 : 1)                                                                \
     }

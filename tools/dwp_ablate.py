@@ -24,7 +24,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     eng.profile_select("dw", 0, 4096); eng.train_resident(0, NB * B); us, n = eng.profile_read(); eng.profile_select(None)
     print(json.dumps({"us": us, "n": n})); sys.exit(0)
 res = {}
-names[64] = "operand LDS writes after the last MFMA instead of inside the block (correct results)"
+names[512] = "operands staged through registers + ds_write_b128 instead of LDS-DMA (correct results)"
+names[576] = "... and written to LDS after the last MFMA instead of inside the block (correct results)"
 names[256] = "update in scalar fp32 instructions instead of packed pairs (correct results)"
 variants = [int(x) for x in sys.argv[1:]] or [0, 1, 2, 3, 4, 16, 48, 7, 15, 31, 63]
 for rnd in range(3 if len(variants) <= 3 else 2):
