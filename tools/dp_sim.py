@@ -19,6 +19,8 @@ for world, sharded in ((1, False), (2, False), (4, False), (8, False), (8, True)
     eng.load_chunk(inp, targ)
     eng.train_resident(0, NB * B); eng.sync()
     eng.profile_select("dw", 0, 4096); eng.train_resident(0, NB * B); us, n = eng.profile_read(); eng.profile_select(None)
-    print("world %d%s: dW launch over %d gathered frames %.1f us incl. ~3.8 us bracket (%d launches)"
-          % (world, " sharded update (rank 3's share only; W all-gather not emulated)" if sharded else "", world * B, us, n), flush=True)
+    steps = NB // world
+    print("world %d%s: dW launches over %d gathered frames %.1f us per step (%d launch%s per step, kernel start/stop events)"
+          % (world, " sharded update (rank 3's share only; W all-gather not emulated)" if sharded else "", world * B,
+             us * n / steps, n // steps, "" if n == steps else "es"), flush=True)
     eng.close()
