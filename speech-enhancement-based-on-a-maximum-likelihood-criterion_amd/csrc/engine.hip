@@ -161,6 +161,7 @@ struct mlggd_engine {
     int fdim = 0, toff = 0, raw_frames = 0;
     unsigned step_counter = 0;
     // launch-plan knobs (defaults chosen from measurements; env overrides for A/B runs)
+    int fwd_pipe = 1, dx_pipe = 1;  // main loops software-pipelined inside the wave (0: the round-1 loops, for A/B)
     int fwd_nw = 8, dx_nw = 8, dw_tile = 1, dw_persist = 1, dwp_per_cu = 2, dw_merge = 1, loss_fuse = 1, tile_map = 0, stage_ahead = 1;  // dw_tile 0 = auto
 
     // data parallel
@@ -241,7 +242,7 @@ static int download_padded(float *dst, const float *src, int Np, int K, int N, h
 
 // ------------------------------------------------------------------ kernel launch plan
 // Times the launches of one kernel class with a pair of HIP events per launch (mlggd_profile_select).
-// The weight-gradient kernels (class "dw") take the pair INTO the launch (hipExtLaunchKernelGGL start / stop
+// The GEMM kernels (classes "dw", "fwd", "dx") take the pair INTO the launch (hipExtLaunchKernelGGL start / stop
 // events = the dispatch's own begin / end timestamps, what rocprofv3 reports as the kernel's duration); the other
 // classes are bracketed by events recorded on the stream before and after, which adds the cost of the bracket.
 struct ProfScope {
@@ -249,7 +250,7 @@ struct ProfScope {
     hipStream_t st;
     bool on, attach;
     ProfScope(mlggd_engine *eng, int cls, int layer, hipStream_t s = nullptr)
-        : e(eng), st(s ? s : eng->stream), on(false), attach(cls == KC_DW) {
+        : e(eng), st(s ? s : eng->stream), on(false), attach(cls == KC_DW || cls == KC_FWD || cls == KC_DX) {
         if (e->prof_class == cls && (e->prof_layer == 0 || e->prof_layer == layer) &&
             e->step_counter % (unsigned)e->prof_stride == 0 && e->prof_used + 2 <= e->prof_ev.size()) {
             on = true;
@@ -271,7 +272,7 @@ struct ProfScope {
         }
     }
 };
-// launch a dW kernel, with the pending event pair of the profiler attached if there is one
+// launch a GEMM kernel, with the pending event pair of the profiler attached if there is one
 template <typename F, typename... Args>
 static void launch_timed(mlggd_engine *e, F kernel, dim3 grid, dim3 block, size_t lds, hipStream_t st, Args... args) {
     if (e->prof_attach && !e->prof_attached) {
@@ -473,20 +474,24 @@ static int run_forward(mlggd_engine *e, const Bunch &bn, int frames, bool traini
             FwdArgs fa = fwd_args(e, l, e->Y[l]);
             if (l != e->L - 1) {
                 long long *st = stamps_for(e, KC_FWD, l, n_tiles * b_tiles);
-#define LAUNCH_FWD(NW)                                                                                      \
+#define LAUNCH_FWD(NW, PIPE)                                                                                \
     {                                                                                                       \
         const size_t lds = fwd_lds_floats<NW>() * sizeof(float);                                            \
-        CHK(ensure_lds(e, k_fwd<FWD_SIGMOID, NW>, lds));                                                       \
-        hipLaunchKernelGGL((k_fwd<FWD_SIGMOID, NW>), dim3(n_tiles * b_tiles), dim3(64 * NW), lds, e->stream, fa, st); \
+        CHK(ensure_lds(e, k_fwd<FWD_SIGMOID, NW, PIPE>, lds));                                              \
+        launch_timed(e, k_fwd<FWD_SIGMOID, NW, PIPE>, dim3(n_tiles * b_tiles), dim3(64 * NW), lds, e->stream, fa, st); \
     }
-                if (e->fwd_nw == 16) LAUNCH_FWD(16)
-                else if (e->fwd_nw == 8) LAUNCH_FWD(8)
-                else LAUNCH_FWD(4)
+                // PIPE 1: main loop software-pipelined inside the wave (default); 0: the round-1 loop (A/B knob
+                // MLGGD_FWD_PIPE=0, and the 16-wave form, whose 128-VGPR budget the pipelined loop does not fit)
+                if (e->fwd_nw == 16) LAUNCH_FWD(16, 0)
+                else if (e->fwd_nw == 8 && e->fwd_pipe) LAUNCH_FWD(8, 1)
+                else if (e->fwd_nw == 8) LAUNCH_FWD(8, 0)
+                else if (e->fwd_pipe) LAUNCH_FWD(4, 1)
+                else LAUNCH_FWD(4, 0)
 #undef LAUNCH_FWD
             } else {
                 const size_t lds = fwd_lds_floats<4>() * sizeof(float);
-                hipLaunchKernelGGL((k_fwd<FWD_SLAB, 4>), dim3(n_tiles * b_tiles * e->S_out), dim3(256), lds, e->stream,
-                                   fa, (long long *)nullptr);
+                launch_timed(e, k_fwd<FWD_SLAB, 4>, dim3(n_tiles * b_tiles * e->S_out), dim3(256), lds, e->stream, fa,
+                             (long long *)nullptr);
             }
         }
         CHK(launch_check("k_fwd"));
@@ -934,15 +939,18 @@ static int run_dx(mlggd_engine *e, int l) {
     ProfScope ps(e, KC_DX, l);
     long long *st = stamps_for(e, KC_DX, l, (Kp / 32) * b_tiles);
     DxArgs xa = dx_args(e, l);
-    if (e->dx_nw == 8) {
-        const size_t lds = dx_lds_floats<8>() * sizeof(float);
-        CHK(ensure_lds(e, k_dx<8>, lds));
-        hipLaunchKernelGGL(k_dx<8>, dim3((Kp / 32) * b_tiles), dim3(512), lds, e->stream, xa, st);
-    } else {
-        const size_t lds = dx_lds_floats<4>() * sizeof(float);
-        CHK(ensure_lds(e, k_dx<4>, lds));
-        hipLaunchKernelGGL(k_dx<4>, dim3((Kp / 32) * b_tiles), dim3(256), lds, e->stream, xa, st);
+#define LAUNCH_DX(NW, PIPE)                                                                                  \
+    {                                                                                                        \
+        const size_t lds = dx_lds_floats<NW>() * sizeof(float);                                              \
+        CHK(ensure_lds(e, k_dx<NW, PIPE>, lds));                                                             \
+        launch_timed(e, k_dx<NW, PIPE>, dim3((Kp / 32) * b_tiles), dim3(64 * NW), lds, e->stream, xa, st);      \
     }
+    // PIPE 1: main loop software-pipelined inside the wave (default); 0: the round-1 loop (MLGGD_DX_PIPE=0, A/B)
+    if (e->dx_nw == 8 && e->dx_pipe) LAUNCH_DX(8, 1)
+    else if (e->dx_nw == 8) LAUNCH_DX(8, 0)
+    else if (e->dx_pipe) LAUNCH_DX(4, 1)
+    else LAUNCH_DX(4, 0)
+#undef LAUNCH_DX
     return launch_check("k_dx");
 }
 
@@ -1221,6 +1229,8 @@ int mlggd_create(const mlggd_config *cfg, const float *const *weights, const flo
     e->Dp = e->lsp[e->L - 1];
     if (const char *v = getenv("MLGGD_FWD_NW")) e->fwd_nw = atoi(v);
     if (const char *v = getenv("MLGGD_DX_NW")) e->dx_nw = atoi(v);
+    if (const char *v = getenv("MLGGD_FWD_PIPE")) e->fwd_pipe = atoi(v) ? 1 : 0;
+    if (const char *v = getenv("MLGGD_DX_PIPE")) e->dx_pipe = atoi(v) ? 1 : 0;
     if (const char *v = getenv("MLGGD_DW_TILE")) e->dw_tile = atoi(v);
     if (const char *v = getenv("MLGGD_TWO_STREAMS")) e->two_streams = atoi(v);
     if (const char *v = getenv("MLGGD_DW_PERSIST")) e->dw_persist = atoi(v);

@@ -105,7 +105,7 @@ struct FwdArgs {
 // LDS floats needed by fwd_body<.,NW>: staging/reduction tiles + the 32x33 transposition tile
 template <int NW> constexpr int fwd_lds_floats() { return NW * 2048 + 32 * 33; }
 
-template <int MODE, int NW>
+template <int MODE, int NW, int PIPE = 1>
 __device__ __forceinline__ void fwd_body(const FwdArgs &A, const int bid, float *smem, long long *stamps) {
     const float *__restrict__ W = A.W, *__restrict__ Yt_in = A.Yt_in, *__restrict__ bias = A.bias;
     float *__restrict__ Yt_out = A.Yt_out, *__restrict__ Y_out = A.Y_out, *__restrict__ slab = A.slab;
@@ -157,6 +157,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &A, const int bid, float 
     for (int q = 0; q < EPT_; q++) bias_pre[q] = MODE == FWD_SIGMOID ? bias[n0 + ((tid + NT_ * q) >> 5)] : 0.0f;
     asm volatile("" ::: "memory");
 
+    if constexpr (PIPE == 0) {
     float4 wa[4], ya[4], wb[4], yb[4];
     // rows past Kp are range-checked zeros; rows past this wave's range are only ever
     // multiplied under the npairs guard of the drain
@@ -205,6 +206,94 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &A, const int bid, float 
 #undef FWD_LOAD
 #undef FWD_WRITE
 #undef FWD_COMPUTE
+    } else {
+    // Main loop, software-pipelined INSIDE the wave (round 2; before, a wave went global -> registers -> LDS ->
+    // fragments -> 16 MFMAs chunk after chunk and issued no MFMA for ~500 cycles at every chunk boundary; the SIMD's
+    // other wave filled those gaps only until the older wave of the pair had finished -- the arbiter prefers it --
+    // and then ran alone at two thirds of the pipe: per-wave stamps showed wave 0 done at 8.4 us and waves 4..7
+    // at 11.7 us of a launch whose MFMA time is 8.0 us).  Now the 16 MFMAs of chunk c run on fragments that are
+    // already in registers, and in their shadow the wave stores chunk c+1 (registers, loaded 1.5 chunks earlier)
+    // to its LDS tile, reads ALL of its fragments back, and refills those registers with chunk c+3: two MFMAs
+    // per group, the other instructions pinned to their group by sched_barrier.  LDS operations of one wave
+    // complete in order, the tile is wave-private: no barrier, no wait between the stores and the reads.
+    // Same MFMA order as before: same bits.
+    float4 wa[4], ya[4], wb[4], yb[4];
+    float fa[16], fb[16], ga[16], gb[16];
+    // rows past Kp are range-checked zeros; rows past this wave's range are only ever
+    // multiplied under the npairs guard of the drain
+#define FWD_LOAD1(WR, YR, C, Q)                                                    \
+    {                                                                              \
+        const int row0 = 2 * (p0 + 16 * (C));                                      \
+        WR[Q] = bload4(rW, voW, (row0 + 8 * (Q)) * Np * 4);                        \
+        YR[Q] = bload4(rY, voY, (row0 + 8 * (Q)) * Bp * 4);                        \
+    }
+#define FWD_WRITE1(WR, YR, Q)                                                      \
+    {                                                                              \
+        *reinterpret_cast<float4 *>(wdst + (Q) * 256) = WR[Q];                     \
+        *reinterpret_cast<float4 *>(wdst + 1024 + (Q) * 256) = YR[Q];              \
+    }
+#define FWD_READ4(NA, NB, Q)                                                       \
+    {                                                                              \
+        _Pragma("unroll") for (int u = 4 * (Q); u < 4 * (Q) + 4; u++) {            \
+            NA[u] = ard[u * 64];                                                   \
+            NB[u] = brd[u * 64];                                                   \
+        }                                                                          \
+    }
+    // chunk C on fragments (FA, FB); chunk C+1 sits in registers (WR, YR) -> LDS -> fragments (NA, NB); (WR, YR)
+    // are then refilled with chunk C+3
+#define FWD_BODY(FA, FB, NA, NB, WR, YR, C)                                        \
+    {                                                                              \
+        _Pragma("unroll") for (int g = 0; g < 4; g++) {                            \
+            acc = mfma32(FA[2 * g], FB[2 * g], acc);                               \
+            acc = mfma32(FA[2 * g + 1], FB[2 * g + 1], acc);                       \
+            FWD_WRITE1(WR, YR, g);                                                 \
+            __builtin_amdgcn_sched_barrier(0);                                     \
+        }                                                                          \
+        _Pragma("unroll") for (int g = 4; g < 8; g++) {                            \
+            acc = mfma32(FA[2 * g], FB[2 * g], acc);                               \
+            acc = mfma32(FA[2 * g + 1], FB[2 * g + 1], acc);                       \
+            FWD_READ4(NA, NB, g - 4);                                              \
+            FWD_LOAD1(WR, YR, (C) + 3, g - 4);                                     \
+            __builtin_amdgcn_sched_barrier(0);                                     \
+        }                                                                          \
+    }
+#define FWD_DRAIN(FA, FB, CNT)                                                     \
+    {                                                                              \
+        _Pragma("unroll") for (int u = 0; u < 16; u++) {                           \
+            if (u < (CNT)) acc = mfma32(FA[u], FB[u], acc);                        \
+        }                                                                          \
+    }
+    if (nch > 0) {
+        const int nfull = npairs >> 4, rem = npairs & 15;
+#pragma unroll
+        for (int q = 0; q < 4; q++) FWD_LOAD1(wa, ya, 0, q);
+#pragma unroll
+        for (int q = 0; q < 4; q++) FWD_LOAD1(wb, yb, 1, q);
+#pragma unroll
+        for (int q = 0; q < 4; q++) FWD_WRITE1(wa, ya, q);
+#pragma unroll
+        for (int q = 0; q < 4; q++) FWD_READ4(fa, fb, q);
+#pragma unroll
+        for (int q = 0; q < 4; q++) FWD_LOAD1(wa, ya, 2, q);
+        __builtin_amdgcn_sched_barrier(0);
+        int c = 0;
+        for (; c + 1 < nfull; c += 2) {
+            FWD_BODY(fa, fb, ga, gb, wb, yb, c);
+            FWD_BODY(ga, gb, fa, fb, wa, ya, c + 1);
+        }
+        if (c < nfull) {
+            FWD_BODY(fa, fb, ga, gb, wb, yb, c);
+            FWD_DRAIN(ga, gb, rem);
+        } else {
+            FWD_DRAIN(fa, fb, rem);
+        }
+    }
+#undef FWD_LOAD1
+#undef FWD_WRITE1
+#undef FWD_READ4
+#undef FWD_BODY
+#undef FWD_DRAIN
+    }
 
     stamp(stamps, 1, bid);
     // cross-wave reduction through LDS (aliases the staging tiles: wait for every wave)
@@ -276,7 +365,7 @@ struct DxArgs {
 };
 template <int NW> constexpr int dx_lds_floats() { return NW * (32 * DX_LDW + 2048) + 32 * 33; }
 
-template <int NW>
+template <int NW, int PIPE = 1>
 __device__ __forceinline__ void dx_body(const DxArgs &A, const int bid, float *smem, long long *stamps) {
     const float *__restrict__ W = A.W, *__restrict__ dEdXt = A.dEdXt, *__restrict__ Yt_prev = A.Yt_prev;
     float *__restrict__ dEdXt_prev = A.dEdXt_prev, *__restrict__ dEdX_prev = A.dEdX_prev;
@@ -335,6 +424,7 @@ __device__ __forceinline__ void dx_body(const DxArgs &A, const int bid, float *s
     }
     asm volatile("" ::: "memory");
 
+    if constexpr (PIPE == 0) {
     float4 wa[8], da[8], wv[8], dv[8];
     // Quads past this wave's range read valid or range-checked-zero data and are only ever
     // multiplied under the count guard of the drain.
@@ -389,6 +479,87 @@ __device__ __forceinline__ void dx_body(const DxArgs &A, const int bid, float *s
 #undef DX_LOAD
 #undef DX_WRITE
 #undef DX_COMPUTE
+    } else {
+    // Software-pipelined inside the wave like fwd_body's loop: the 32 MFMAs of chunk c (16 quads = 64 n) run on
+    // fragments already in registers; in their shadow chunk c+1 goes registers -> LDS (groups 0..7) -> fragments
+    // (groups 8..15) and the staging registers are refilled with chunk c+2 four groups after they were stored
+    // (1.5 us of lead at two waves per SIMD).  One staging set instead of two pays for the second fragment set.
+    // Same MFMA order as the round-1 loop: same bits.
+    float4 wa[8], da[8];
+    float fa[32], fb[32], ga[32], gb[32];
+#define DX_LOAD1(C, IT)                                                                    \
+    {                                                                                      \
+        const int quad0 = q0 + (C)*16;                                                     \
+        wa[IT] = bload4(rW, voW, quad0 * 16 + (IT) * (16 * Np));                           \
+        da[IT] = bload4(rD, voD, (4 * quad0 + 8 * (IT)) * Bp * 4);                         \
+    }
+#define DX_WRITE1(IT)                                                                      \
+    {                                                                                      \
+        float *dst = wdst + (4 * (IT)) * DX_LDW;                                           \
+        *reinterpret_cast<float2 *>(dst + wsw) = make_float2(wa[IT].x, wa[IT].y);          \
+        *reinterpret_cast<float2 *>(dst + (2 - wsw)) = make_float2(wa[IT].z, wa[IT].w);    \
+        *reinterpret_cast<float4 *>(ddst + (IT) * 256) = da[IT];                           \
+    }
+#define DX_READ1(NA, NB, J)                                                                \
+    {                                                                                      \
+        const float2 av = *reinterpret_cast<const float2 *>(((J) < 8 ? ard : ard_hi) + 4 * (J)); \
+        NA[2 * (J)] = av.x;                                                                \
+        NA[2 * (J) + 1] = av.y;                                                            \
+        NB[2 * (J)] = brd[(4 * (J)) * 32];                                                 \
+        NB[2 * (J) + 1] = brd[(4 * (J) + 2) * 32];                                         \
+    }
+#define DX_BODY(FA, FB, NA, NB, C)                                                         \
+    {                                                                                      \
+        _Pragma("unroll") for (int g = 0; g < 16; g++) {                                   \
+            acc = mfma32(FA[2 * g], FB[2 * g], acc);                                       \
+            acc = mfma32(FA[2 * g + 1], FB[2 * g + 1], acc);                               \
+            if (g < 8) DX_WRITE1(g);                                                       \
+            if (g >= 4 && g < 12) DX_LOAD1((C) + 2, g - 4);                                \
+            if (g >= 8) {                                                                  \
+                DX_READ1(NA, NB, 2 * (g - 8));                                             \
+                DX_READ1(NA, NB, 2 * (g - 8) + 1);                                         \
+            }                                                                              \
+            __builtin_amdgcn_sched_barrier(0);                                             \
+        }                                                                                  \
+    }
+#define DX_DRAIN(FA, FB, CNT)                                                              \
+    {                                                                                      \
+        _Pragma("unroll") for (int j = 0; j < 16; j++) {                                   \
+            if (j < (CNT)) {                                                               \
+                acc = mfma32(FA[2 * j], FB[2 * j], acc);                                   \
+                acc = mfma32(FA[2 * j + 1], FB[2 * j + 1], acc);                           \
+            }                                                                              \
+        }                                                                                  \
+    }
+    if (nch > 0) {
+        const int nfull = myq >> 4, rem = myq & 15;
+#pragma unroll
+        for (int it = 0; it < 8; it++) DX_LOAD1(0, it);
+#pragma unroll
+        for (int it = 0; it < 8; it++) DX_WRITE1(it);
+#pragma unroll
+        for (int j = 0; j < 16; j++) DX_READ1(fa, fb, j);
+#pragma unroll
+        for (int it = 0; it < 8; it++) DX_LOAD1(1, it);
+        __builtin_amdgcn_sched_barrier(0);
+        int c = 0;
+        for (; c + 1 < nfull; c += 2) {
+            DX_BODY(fa, fb, ga, gb, c);
+            DX_BODY(ga, gb, fa, fb, c + 1);
+        }
+        if (c < nfull) {
+            DX_BODY(fa, fb, ga, gb, c);
+            DX_DRAIN(ga, gb, rem);
+        } else {
+            DX_DRAIN(fa, fb, rem);
+        }
+    }
+#undef DX_LOAD1
+#undef DX_WRITE1
+#undef DX_READ1
+#undef DX_BODY
+#undef DX_DRAIN
+    }
 
     stamp(stamps, 1, bid);
     __syncthreads();
@@ -1103,13 +1274,13 @@ __device__ __forceinline__ void dwp_body(const DwpDesc *__restrict__ table, cons
 // ---------------------------------------------------------------------------------------
 extern __shared__ __attribute__((aligned(16))) float g_dyn_lds[];
 
-template <int MODE, int NW>
+template <int MODE, int NW, int PIPE = 1>
 __global__ __launch_bounds__(64 * NW) void k_fwd(FwdArgs A, long long *stamps) {
-    fwd_body<MODE, NW>(A, (int)blockIdx.x, g_dyn_lds, stamps);
+    fwd_body<MODE, NW, PIPE>(A, (int)blockIdx.x, g_dyn_lds, stamps);
 }
-template <int NW>
+template <int NW, int PIPE = 1>
 __global__ __launch_bounds__(64 * NW) void k_dx(DxArgs A, long long *stamps) {
-    dx_body<NW>(A, (int)blockIdx.x, g_dyn_lds, stamps);
+    dx_body<NW, PIPE>(A, (int)blockIdx.x, g_dyn_lds, stamps);
 }
 template <int H, bool FUSED, bool POW2>
 __global__ __launch_bounds__(256) void k_dwp(const DwpDesc *__restrict__ table, int total, DwpConst C, long long *stamps) {

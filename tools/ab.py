@@ -28,9 +28,12 @@ for rnd in range(2):
         for _ in range(8): eng.train_resident(0, NB * B)
         eng.sync(); dt = (time.perf_counter() - t0) / (8 * NB)
         per = {}
-        for cls in ("fwd", "dx", "dw"):
-            eng.profile_select(cls, 0, 4096); eng.train_resident(0, NB * B); us, n = eng.profile_read(); per[cls] = us
+        for cls, layers in (("fwd", range(1, len(ls))), ("dx", range(2, len(ls))), ("dw", (0,))):
+            for l in layers:  # kernel-own start/stop events (hipExtLaunchKernelGGL), one (class, layer) at a time
+                eng.profile_select(cls, l, 4096); eng.train_resident(0, NB * B); us, n = eng.profile_read(); per[cls, l] = us
         eng.profile_select(None)
-        print("round %d %s: %.1f us/step  fwd %.1f dx %.1f dw %.1f us  (W2 relerr vs first %.1e)" %
-              (rnd, " ".join("%s=%s" % (k[6:], v) for k, v in cfg.items()), dt * 1e6, per["fwd"], per["dx"], per["dw"], err), flush=True)
+        print("round %d %s: %.1f us/step  fwd %s  dx %s  dw %.1f us  (W2 relerr vs first %.1e)" %
+              (rnd, " ".join("%s=%s" % (k[6:], v) for k, v in cfg.items()), dt * 1e6,
+               "/".join("%.2f" % per["fwd", l] for l in range(1, len(ls))), "/".join("%.2f" % per["dx", l] for l in range(2, len(ls))),
+               per["dw", 0], err), flush=True)
         eng.close()
