@@ -301,6 +301,11 @@ static int ensure_lds(mlggd_engine *e, F fn, size_t bytes) {
     return MLGGD_OK;
 }
 
+static int log2_or_minus1(int d) {  // for divmod_by in the kernels
+    for (int sft = 0; sft < 31; sft++)
+        if (d == (1 << sft)) return sft;
+    return -1;
+}
 static FwdArgs fwd_args(mlggd_engine *e, int l, float *Yrow_out) {
     FwdArgs a;
     a.W = e->W[l];
@@ -317,6 +322,8 @@ static FwdArgs fwd_args(mlggd_engine *e, int l, float *Yrow_out) {
     a.b_tiles = e->Bp / 32;
     a.S = (l == e->L - 1) ? e->S_out : 1;
     a.map = e->tile_map;
+    a.b_shift = log2_or_minus1(a.b_tiles);
+    a.s_shift = log2_or_minus1(a.S);
     return a;
 }
 
@@ -333,6 +340,7 @@ static DxArgs dx_args(mlggd_engine *e, int l) {
     a.k_tiles = e->lsp[l - 1] / 32;
     a.b_tiles = e->Bp / 32;
     a.map = e->tile_map;
+    a.b_shift = log2_or_minus1(a.b_tiles);
     return a;
 }
 

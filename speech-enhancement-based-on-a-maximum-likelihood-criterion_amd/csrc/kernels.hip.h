@@ -29,15 +29,27 @@ __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (
 // ids that are equal mod 8 and adjacent in dispatch order, so they land on one XCD and the
 // tile is fetched from HBM/MALL once and re-read from that XCD's L2 (speed only; any
 // placement is correct).
-__device__ __forceinline__ void tile_of_block(int id, int u_tiles, int b_tiles, int &ut, int &bt, int map = 0) {
+// x / d and x % d for a divisor the host has looked at: shift >= 0 means d == 1 << shift.  (A runtime integer
+// division is ~40 scalar instructions on this ISA, a 64-bit one ~200: the prologue of the forward kernel spent
+// ~1 us -- a tenth of the launch -- dividing before its first load was issued.)
+__device__ __forceinline__ void divmod_by(int x, int d, int shift, int &q, int &r) {
+    if (shift >= 0) {
+        q = x >> shift;
+        r = x & (d - 1);
+    } else {
+        q = (int)((unsigned)x / (unsigned)d);
+        r = x - q * d;
+    }
+}
+__device__ __forceinline__ void tile_of_block(int id, int u_tiles, int b_tiles, int b_shift, int &ut, int &bt, int map = 0) {
     if ((u_tiles & 7) == 0 && map != 2) {
         const int xcd = id & 7, slot = id >> 3;
         // map 0: an XCD owns unit tiles xcd, xcd+8, ...; map 1: a contiguous run of u_tiles/8 tiles
-        ut = map == 1 ? xcd * (u_tiles >> 3) + slot / b_tiles : xcd + 8 * (slot / b_tiles);
-        bt = slot % b_tiles;
+        int q;
+        divmod_by(slot, b_tiles, b_shift, q, bt);
+        ut = map == 1 ? xcd * (u_tiles >> 3) + q : xcd + 8 * q;
     } else {
-        ut = id / b_tiles;
-        bt = id % b_tiles;
+        divmod_by(id, b_tiles, b_shift, ut, bt);
     }
 }
 
@@ -101,6 +113,7 @@ struct FwdArgs {
     const float *W, *Yt_in, *bias;
     float *Yt_out, *Y_out, *slab;
     int Kp, Np, Bp, N, n_tiles, b_tiles, S, map;
+    int b_shift, s_shift;  // log2 of b_tiles / S when they are powers of two, else -1 (divmod_by)
 };
 // LDS floats needed by fwd_body<.,NW>: staging/reduction tiles + the 32x33 transposition tile
 template <int NW> constexpr int fwd_lds_floats() { return NW * 2048 + 32 * 33; }
@@ -118,18 +131,24 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &A, const int bid, float 
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
     const int i = lane & 31, h = lane >> 5;
     int id = bid, s = 0;
-    if (MODE == FWD_SLAB) {
-        s = id % S;
-        id /= S;
-    }
+    if (MODE == FWD_SLAB) divmod_by(bid, S, A.s_shift, id, s);
     int nt, bt;
-    tile_of_block(id, n_tiles, b_tiles, nt, bt, A.map);
+    tile_of_block(id, n_tiles, b_tiles, A.b_shift, nt, bt, A.map);
     const int n0 = nt * 32, b0 = bt * 32;
 
     // k-pairs of this wave: slot = s*NW+wave of S*NW slots over Kp/2 pairs
     const int P = Kp >> 1;
     const int slot = s * NW + wave, nslots = S * NW;
-    const int p0 = (int)((long)P * slot / nslots), p1 = (int)((long)P * (slot + 1) / nslots);
+    // floor(P * slot / nslots) in 32 bits (P * nslots < 2^31 for any layer this engine accepts); without slabs the
+    // divisor is the compile-time wave count
+    int p0, p1;
+    if (MODE == FWD_SLAB) {
+        p0 = (int)((unsigned)(P * slot) / (unsigned)nslots);
+        p1 = (int)((unsigned)(P * (slot + 1)) / (unsigned)nslots);
+    } else {
+        p0 = (int)((unsigned)(P * wave) / (unsigned)NW);
+        p1 = (int)((unsigned)(P * (wave + 1)) / (unsigned)NW);
+    }
     const int npairs = p1 - p0;
     const int nch = (npairs + 15) >> 4;  // chunks of 16 pairs = 32 k rows
 
@@ -361,7 +380,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &A, const int bid, float 
 struct DxArgs {
     const float *W, *dEdXt, *Yt_prev;
     float *dEdXt_prev, *dEdX_prev;
-    int Kp, Np, Bp, k_tiles, b_tiles, map;
+    int Kp, Np, Bp, k_tiles, b_tiles, map, b_shift;
 };
 template <int NW> constexpr int dx_lds_floats() { return NW * (32 * DX_LDW + 2048) + 32 * 33; }
 
@@ -377,7 +396,7 @@ __device__ __forceinline__ void dx_body(const DxArgs &A, const int bid, float *s
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
     const int i = lane & 31, h = lane >> 5;
     int kt, bt;
-    tile_of_block(bid, k_tiles, b_tiles, kt, bt, A.map);
+    tile_of_block(bid, k_tiles, b_tiles, A.b_shift, kt, bt, A.map);
     const int k0 = kt * 32, b0 = bt * 32;
 
     const int Q = Np >> 2;             // quads of 4 consecutive n
