@@ -240,11 +240,16 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &A, const int bid, float 
     float fa[16], fb[16], ga[16], gb[16];
     // rows past Kp are range-checked zeros; rows past this wave's range are only ever
     // multiplied under the npairs guard of the drain
+    // A chunk past this wave's last one is "loaded" from the end of the buffer: out of range for the resource, so it
+    // returns zeros without a memory request (the pipelined body prefetches three chunks ahead unconditionally --
+    // a branch would split its basic block -- and those three would otherwise be the NEXT wave's rows: +37 % traffic)
+    const int endW = Kp * Np * 4, endY = Kp * Bp * 4;
 #define FWD_LOAD1(WR, YR, C, Q)                                                    \
     {                                                                              \
         const int row0 = 2 * (p0 + 16 * (C));                                      \
-        WR[Q] = bload4(rW, voW, (row0 + 8 * (Q)) * Np * 4);                        \
-        YR[Q] = bload4(rY, voY, (row0 + 8 * (Q)) * Bp * 4);                        \
+        const bool live = (C) < nch;                                               \
+        WR[Q] = bload4(rW, voW, live ? (row0 + 8 * (Q)) * Np * 4 : endW);          \
+        YR[Q] = bload4(rY, voY, live ? (row0 + 8 * (Q)) * Bp * 4 : endY);          \
     }
 #define FWD_WRITE1(WR, YR, Q)                                                      \
     {                                                                              \
@@ -506,11 +511,14 @@ __device__ __forceinline__ void dx_body(const DxArgs &A, const int bid, float *s
     // Same MFMA order as the round-1 loop: same bits.
     float4 wa[8], da[8];
     float fa[32], fb[32], ga[32], gb[32];
+    // chunks past this wave's last one: from the end of the buffer = zeros without a memory request (see fwd_body)
+    const int endW = Kp * Np * 4, endD = Np * Bp * 4;
 #define DX_LOAD1(C, IT)                                                                    \
     {                                                                                      \
         const int quad0 = q0 + (C)*16;                                                     \
-        wa[IT] = bload4(rW, voW, quad0 * 16 + (IT) * (16 * Np));                           \
-        da[IT] = bload4(rD, voD, (4 * quad0 + 8 * (IT)) * Bp * 4);                         \
+        const bool live = (C) < nch;                                                       \
+        wa[IT] = bload4(rW, voW, live ? quad0 * 16 + (IT) * (16 * Np) : endW);             \
+        da[IT] = bload4(rD, voD, live ? (4 * quad0 + 8 * (IT)) * Bp * 4 : endD);           \
     }
 #define DX_WRITE1(IT)                                                                      \
     {                                                                                      \
