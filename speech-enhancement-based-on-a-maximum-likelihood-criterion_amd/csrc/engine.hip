@@ -162,7 +162,9 @@ struct mlggd_engine {
     unsigned step_counter = 0;
     // launch-plan knobs (defaults chosen from measurements; env overrides for A/B runs)
     int fwd_pipe = 1, dx_pipe = 1;  // main loops software-pipelined inside the wave (0: the round-1 loops, for A/B)
-    int fwd_nw = 8, dx_nw = 8, dw_tile = 1, dw_persist = 1, dwp_per_cu = 2, dw_merge = 1, loss_fuse = 1, tile_map = 0, stage_ahead = 1;  // dw_tile 0 = auto
+    // 4 waves per workgroup (one per SIMD) since the main loops are pipelined inside the wave: a wave no longer needs a
+    // partner on its SIMD to fill its chunk-boundary gaps, and four partial tiles reduce faster than eight
+    int fwd_nw = 4, dx_nw = 4, dw_tile = 1, dw_persist = 1, dwp_per_cu = 2, dw_merge = 1, loss_fuse = 1, tile_map = 0, stage_ahead = 1;  // dw_tile 0 = auto
 
     // data parallel
     int world = 1, rank = 0;
