@@ -62,6 +62,11 @@ for case in range(N):
     worst = max(worst, err)
     # one-frame minibatches take steps of the order of the weights themselves: rounding differences are amplified
     tol = 2e-5 if B >= 7 else 2e-4
+    if ml == 1 and beta < 1.0:
+        # the beta < 1 gradient sgn(e)|e|^(beta-1) is largest, and changes sign, where e -> 0: an output that differs
+        # in its last bits (GEMM summation order) flips one such element and moves a bias by ~1e-4 of max|b| in a few
+        # steps (SEED=22 case 12: out equal to 7e-7, alpha to 1e-7, one of 7,424 gradient elements with the other sign)
+        tol = 5e-4
     tag = "ok " if err < tol else "BAD"
     print("%s case %2d: layers %-28s B %3d  loss (%d,%.1f) steps %d world %d%s%s  err %.1e" %
           (tag, case, ls, B, ml, beta, steps, world, " " + dp if dp else "", " frames" if frames_mode else "", err),
