@@ -116,7 +116,7 @@ struct FwdArgs {
     int b_shift, s_shift;  // log2 of b_tiles / S when they are powers of two, else -1 (divmod_by)
 };
 // LDS floats needed by fwd_body<.,NW>: staging/reduction tiles + the 32x33 transposition tile
-template <int NW> constexpr int fwd_lds_floats() { return NW * 2048 + 32 * 33; }
+template <int NW> constexpr int fwd_lds_floats() { return NW * 2048 + 32 * 36; }
 
 template <int MODE, int NW, int PIPE = 1>
 __device__ __forceinline__ void fwd_body(const FwdArgs &A, const int bid, float *smem, long long *stamps) {
@@ -125,7 +125,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &A, const int bid, float 
     const int Kp = A.Kp, Np = A.Np, Bp = A.Bp, N = A.N, n_tiles = A.n_tiles, b_tiles = A.b_tiles, S = A.S;
     // per wave: [32 k rows][32] of W then [32 k rows][32] of Yt (8 KB); the cross-wave
     // reduction buffer red[NW][1024] aliases the same storage after the main loop
-    float(*tileT)[33] = reinterpret_cast<float(*)[33]>(smem + NW * 2048);
+    float(*tileT)[36] = reinterpret_cast<float(*)[36]>(smem + NW * 2048);
     stamp(stamps, 0, bid);
     stamp_clk(stamps, 4, bid);
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
@@ -174,6 +174,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &A, const int bid, float 
     float bias_pre[EPT_];
 #pragma unroll
     for (int q = 0; q < EPT_; q++) bias_pre[q] = MODE == FWD_SIGMOID ? bias[n0 + ((tid + NT_ * q) >> 5)] : 0.0f;
+    const float bias_row = (MODE == FWD_SIGMOID && NW == 4) ? bias[n0 + (tid >> 3)] : 0.0f;  // 4-wave epilogue
     asm volatile("" ::: "memory");
 
     if constexpr (PIPE == 0) {
@@ -327,6 +328,43 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &A, const int bid, float 
     for (int r = 0; r < 16; r++) red[wave][acc_row(r, lane) * 32 + i] = acc[r];
     __syncthreads();
     stamp(stamps, 2, bid);
+    if constexpr (NW == 4) {
+        // 256 threads: a thread owns 4 consecutive frames of one unit.  The four partial tiles come in with one
+        // ds_read_b128 each (added in wave order, as below), both output layouts leave as 16-byte stores
+        // (11 LDS / memory instructions per thread instead of 32)
+        const int row = tid >> 3, col4 = (tid & 7) * 4;
+        float4 v4 = *reinterpret_cast<const float4 *>(&red[0][row * 32 + col4]);
+#pragma unroll
+        for (int w = 1; w < NW; w++) {
+            const float4 p4 = *reinterpret_cast<const float4 *>(&red[w][row * 32 + col4]);
+            v4.x += p4.x;
+            v4.y += p4.y;
+            v4.z += p4.z;
+            v4.w += p4.w;
+        }
+        if (MODE == FWD_SLAB) {
+            *reinterpret_cast<float4 *>(&slab[((size_t)s * Np + n0 + row) * Bp + b0 + col4]) = v4;
+        } else {
+            const int n = n0 + row;
+            float4 y4;  // kernSigmoid, DevFunc.cu:48
+            y4.x = (n < N) ? 1.0f / (1.0f + expf(-(v4.x + bias_row))) : 0.0f;
+            y4.y = (n < N) ? 1.0f / (1.0f + expf(-(v4.y + bias_row))) : 0.0f;
+            y4.z = (n < N) ? 1.0f / (1.0f + expf(-(v4.z + bias_row))) : 0.0f;
+            y4.w = (n < N) ? 1.0f / (1.0f + expf(-(v4.w + bias_row))) : 0.0f;
+            *reinterpret_cast<float4 *>(&Yt_out[(size_t)n * Bp + b0 + col4]) = y4;
+            tileT[col4][row] = y4.x;
+            tileT[col4 + 1][row] = y4.y;
+            tileT[col4 + 2][row] = y4.z;
+            tileT[col4 + 3][row] = y4.w;
+            __syncthreads();
+            // thread -> frame row, 4 consecutive units
+            *reinterpret_cast<float4 *>(&Y_out[(size_t)(b0 + row) * Np + n0 + col4]) =
+                *reinterpret_cast<const float4 *>(&tileT[row][col4]);
+        }
+        stamp(stamps, 3, bid);
+        stamp_clk(stamps, 6, bid);
+        return;
+    }
     // 1024 tile elements over 64*NW threads; partial sums added in wave order (deterministic)
     constexpr int NT = 64 * NW, EPT = 1024 / NT > 0 ? 1024 / NT : 1;
     float v[EPT];
@@ -387,7 +425,7 @@ struct DxArgs {
     float *dEdXt_prev, *dEdX_prev;
     int Kp, Np, Bp, k_tiles, b_tiles, map, b_shift;
 };
-template <int NW> constexpr int dx_lds_floats() { return NW * (32 * DX_LDW + 2048) + 32 * 33; }
+template <int NW> constexpr int dx_lds_floats() { return NW * (32 * DX_LDW + 2048) + 32 * 36; }
 
 template <int NW, int PIPE = 1>
 __device__ __forceinline__ void dx_body(const DxArgs &A, const int bid, float *smem, long long *stamps) {
@@ -396,7 +434,7 @@ __device__ __forceinline__ void dx_body(const DxArgs &A, const int bid, float *s
     const int Kp = A.Kp, Np = A.Np, Bp = A.Bp, k_tiles = A.k_tiles, b_tiles = A.b_tiles;
     // per wave: W piece [32][66] (2112 floats) + dEdXt piece [64 n][32] (2048 floats)
     constexpr int WSZ = 32 * DX_LDW, STG = WSZ + 2048;
-    float(*tileT)[33] = reinterpret_cast<float(*)[33]>(smem + NW * STG);
+    float(*tileT)[36] = reinterpret_cast<float(*)[36]>(smem + NW * STG);
     stamp(stamps, 0, bid);
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
     const int i = lane & 31, h = lane >> 5;
@@ -441,10 +479,15 @@ __device__ __forceinline__ void dx_body(const DxArgs &A, const int bid, float *s
     constexpr int NT_ = 64 * NW, EPT_ = 1024 / NT_ > 0 ? 1024 / NT_ : 1;
     static_assert(1024 % NT_ == 0, "every thread owns EPT_ whole output elements");
     float y_pre[EPT_];
+    float4 y_pre4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // 4-wave epilogue: 4 consecutive frames of one unit
+    if constexpr (NW == 4) {
+        y_pre4 = *reinterpret_cast<const float4 *>(&Yt_prev[(size_t)(k0 + (tid >> 3)) * Bp + b0 + (tid & 7) * 4]);
+    } else {
 #pragma unroll
-    for (int q = 0; q < EPT_; q++) {
-        const int e_ = tid + NT_ * q;
-        y_pre[q] = Yt_prev[(size_t)(k0 + (e_ >> 5)) * Bp + b0 + (e_ & 31)];
+        for (int q = 0; q < EPT_; q++) {
+            const int e_ = tid + NT_ * q;
+            y_pre[q] = Yt_prev[(size_t)(k0 + (e_ >> 5)) * Bp + b0 + (e_ & 31)];
+        }
     }
     asm volatile("" ::: "memory");
 
@@ -595,6 +638,33 @@ __device__ __forceinline__ void dx_body(const DxArgs &A, const int bid, float *s
     for (int r = 0; r < 16; r++) red[wave][acc_row(r, lane) * 32 + i] = acc[r];
     __syncthreads();
     stamp(stamps, 2, bid);
+    if constexpr (NW == 4) {  // see fwd_body: ds_read_b128 of the partial tiles, 16-byte stores of both layouts
+        const int row = tid >> 3, col4 = (tid & 7) * 4;
+        float4 d4 = *reinterpret_cast<const float4 *>(&red[0][row * 32 + col4]);
+#pragma unroll
+        for (int w = 1; w < NW; w++) {
+            const float4 p4 = *reinterpret_cast<const float4 *>(&red[w][row * 32 + col4]);
+            d4.x += p4.x;
+            d4.y += p4.y;
+            d4.z += p4.z;
+            d4.w += p4.w;
+        }
+        float4 g4;  // kernDsigmoid, DevFunc.cu:67-68
+        g4.x = (1.0f - y_pre4.x) * y_pre4.x * d4.x;
+        g4.y = (1.0f - y_pre4.y) * y_pre4.y * d4.y;
+        g4.z = (1.0f - y_pre4.z) * y_pre4.z * d4.z;
+        g4.w = (1.0f - y_pre4.w) * y_pre4.w * d4.w;
+        *reinterpret_cast<float4 *>(&dEdXt_prev[(size_t)(k0 + row) * Bp + b0 + col4]) = g4;
+        tileT[col4][row] = g4.x;
+        tileT[col4 + 1][row] = g4.y;
+        tileT[col4 + 2][row] = g4.z;
+        tileT[col4 + 3][row] = g4.w;
+        __syncthreads();
+        *reinterpret_cast<float4 *>(&dEdX_prev[(size_t)(b0 + row) * Kp + k0 + col4]) =
+            *reinterpret_cast<const float4 *>(&tileT[row][col4]);
+        stamp(stamps, 3, bid);
+        return;
+    }
     constexpr int NT = 64 * NW, EPT = 1024 / NT > 0 ? 1024 / NT : 1;
 #pragma unroll
     for (int q = 0; q < EPT; q++) {
