@@ -115,6 +115,44 @@ def test_largest_advertised_bunch_with_the_ml_loss(pkg, pyoracle, synth):
         pkg.BPGpu(1, 0, [70, 130, 64, 33], 1153, 0.1, 0.9, 0.0, ws, bs, 1.2, 1)
 
 
+def test_forward_and_dx_loop_variants(pkg, pyoracle, synth, monkeypatch):
+    """The forward / dX main loops exist in two forms (software-pipelined inside the wave = default, and the round-1
+    loop behind MLGGD_FWD_PIPE=0 / MLGGD_DX_PIPE=0) and for 4 (default) or 8 waves per workgroup.  The pipelined loop
+    issues the same MFMAs in the same order: bit-identical weights for the same wave count.  Another wave count is
+    another K split (summation order): equal to rounding, and each within the oracle bound.  Layer widths chosen so
+    that a wave's K range is several full chunks plus a partial one, a single partial chunk, and nothing at all."""
+    ls, B = [1210, 1060, 70, 262, 40], 96
+    ws, bs = synth.make_weights(ls, seed=31)
+    rng = np.random.default_rng(32)
+    bs = [rng.uniform(-0.1, 0.1, b.shape).astype(np.float32) for b in bs]
+    inp, targ = synth.make_frames(3 * B, 40, 1, seed=33)
+    inp = np.ascontiguousarray(np.tile(inp, (1, 31))[:, :1210])
+
+    def run(env):
+        for k in ("MLGGD_FWD_PIPE", "MLGGD_DX_PIPE", "MLGGD_FWD_NW", "MLGGD_DX_NW"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = pkg.BPGpu(1, 0, ls, B, 0.1, 0.9, 1e-5, ws, bs, 1.2, 1)
+        assert eng.train(inp, targ) == 3
+        w, b = eng.returnWeights()
+        eng.close()
+        return w + b
+
+    ora = pyoracle.OracleNet(ls, B, 0.1, 0.9, 1e-5, 1.2, 1, ws, bs)
+    assert ora.train(inp, targ) == 3
+    wo, bo = ora.get_weights()
+    old = {"MLGGD_FWD_PIPE": "0", "MLGGD_DX_PIPE": "0"}
+    for nw in ("4", "8"):
+        waves = {"MLGGD_FWD_NW": nw, "MLGGD_DX_NW": nw}
+        new_loop, old_loop = run(waves), run(dict(waves, **old))
+        for x, y in zip(new_loop, old_loop):
+            assert np.array_equal(x, y), nw
+        for x, y in zip(new_loop, wo + bo):
+            assert relmax(x, y) < 2e-5, nw
+    ora.close()
+
+
 @pytest.mark.parametrize("ml,beta", [(0, 2.0), (1, 1.2)])
 def test_baseline_net_two_steps(pkg, pyoracle, synth, ml, beta):
     """BASELINE.json configs 2/3: 2827-2048x3-257, 128-frame minibatch."""
