@@ -1214,6 +1214,13 @@ int mlggd_create(const mlggd_config *cfg, const float *const *weights, const flo
     if (cfg->bunchsize < 1) return fail(MLGGD_ERR_ARG, "bunchsize %d < 1", cfg->bunchsize);
     for (int i = 0; i < cfg->numlayers; i++)
         if (cfg->layersizes[i] < 1) return fail(MLGGD_ERR_ARG, "layersizes[%d] = %d", i, cfg->layersizes[i]);
+    for (int i = 1; i < cfg->numlayers; i++) {
+        // the kernels address a weight matrix with 32-bit byte offsets into one buffer resource
+        const long long bytes = 4ll * ceil32(cfg->layersizes[i - 1]) * ceil32(cfg->layersizes[i]);
+        if (bytes >= (1ll << 31))
+            return fail(MLGGD_ERR_ARG, "layer %d: %d x %d weights exceed the 2 GiB a kernel can address", i,
+                        cfg->layersizes[i - 1], cfg->layersizes[i]);
+    }
     if (ceil32(cfg->bunchsize) > 1152)  // LOSS_LDS_MAX: 32 columns x (1152 + 1) frames of the loss kernels' LDS tile
         return fail(MLGGD_ERR_ARG, "bunchsize %d too large for the loss kernel's LDS tile (max 1152)", cfg->bunchsize);
     int ndev = 0;

@@ -58,3 +58,29 @@ def test_shard_rows(pkg):
     assert [pkg.shard_rows(1024, 8, r) for r in (0, 3, 7)] == [(0, 128), (384, 512), (896, 1024)]
     with pytest.raises(ValueError):
         pkg.shard_rows(100, 8, 0)
+
+
+def test_create_rejects_bad_arguments_before_touching_a_device(pkg):
+    """Argument checks of mlggd_create that need no GPU: a bunch larger than the loss kernels' LDS tile, a layer
+    whose padded weight matrix a kernel could not address with 32-bit byte offsets."""
+    L = pkg.load()
+    fp = ctypes.POINTER(ctypes.c_float)
+    arr = (fp * pkg.MAXLAYER)()  # never dereferenced: the checks come first
+
+    def create(layersizes, bunch):
+        cfg = pkg._Config()
+        cfg.struct_size = ctypes.sizeof(pkg._Config)
+        cfg.numlayers = len(layersizes)
+        for i, v in enumerate(layersizes):
+            cfg.layersizes[i] = v
+        cfg.bunchsize = bunch
+        h = ctypes.c_void_p()
+        rc = L.mlggd_create(ctypes.byref(cfg), arr, arr, ctypes.byref(h))
+        return rc, L.mlggd_last_error().decode()
+
+    rc, msg = create([30000, 30000, 257], 128)
+    assert rc != 0 and "2 GiB" in msg
+    rc, msg = create([100, 50, 10], 1153)
+    assert rc != 0 and "too large" in msg
+    rc, msg = create([100, 0, 10], 8)
+    assert rc != 0 and "layersizes[1]" in msg
