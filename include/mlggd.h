@@ -162,9 +162,12 @@ int mlggd_comm_init(mlggd_handle h, const void *id, int world_size, int rank);
 int mlggd_last_train_ms(mlggd_handle h, float *ms, int *steps);
 
 /* Kernel-class timing INSIDE a timed mlggd_train_resident region (bench.py's roofline
- * object): mlggd_profile_select brackets every launch of the named class ("transpose" "fwd"
- * "loss" "dx" "dw" "update"; layer 0 = all layers) with HIP events on the engine's
- * stream, up to max_launches; NULL/"" switches it off.  mlggd_profile_read syncs and returns
+ * object): mlggd_profile_select times every launch of the named class ("transpose" "fwd"
+ * "loss" "dx" "dw" "update"; layer 0 = all layers) with a pair of HIP events, up to
+ * max_launches; NULL/"" switches it off.  The GEMM classes ("fwd" "dx" "dw") take the pair INTO
+ * the launch (hipExtLaunchKernelGGL start/stop events = the dispatch's own begin/end timestamps,
+ * what rocprofv3 --kernel-trace reports); the other classes are bracketed by events recorded on
+ * the stream before and after, which adds the bracket's cost.  mlggd_profile_read syncs and returns
  * the mean launch duration in microseconds and the number of launches seen.
  * mlggd_kernel_work gives the algorithmic FLOPs / bytes of ONE launch of (class, layer)
  * (layer 0 = summed over layers), the figures DESIGN.md states per kernel. */
