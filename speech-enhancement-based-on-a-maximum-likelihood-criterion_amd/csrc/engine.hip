@@ -1290,10 +1290,13 @@ int mlggd_create(const mlggd_config *cfg, const float *const *weights, const flo
     {
         const int tiles = (e->Dp / 32) * (Bp / 32);
         const int pairs = e->lsp[L - 2] / 2;
-        int S = (256 + tiles - 1) / tiles;
+        // one round of workgroups on the 256 CUs when that still splits K at least four ways (36 tiles: 7 x 36 = 252
+        // workgroups; 8 x 36 = 288 left 32 of them for a second round: +1 us per step), else enough to fill the chip
+        int S = 256 / tiles >= 4 ? 256 / tiles : (256 + tiles - 1) / tiles;
         if (S > pairs / 16) S = pairs / 16;  // >= 4 k-pairs per wave
         if (S < 1) S = 1;
         if (S > 32) S = 32;
+        if (const char *v = getenv("MLGGD_S_OUT")) S = atoi(v) < 1 ? 1 : atoi(v) > 32 ? 32 : atoi(v);  // A/B knob
         e->S_out = S;
     }
     CHK(dev_alloc(e, &e->slab, (size_t)e->S_out * e->Dp * Bp));
