@@ -161,7 +161,7 @@ struct mlggd_engine {
     int fdim = 0, toff = 0, raw_frames = 0;
     unsigned step_counter = 0;
     // launch-plan knobs (defaults chosen from measurements; env overrides for A/B runs)
-    int fwd_pipe = 1, dx_pipe = 1;  // main loops software-pipelined inside the wave (0: the round-1 loops, for A/B)
+    int fwd_pipe = 4, dx_pipe = 1;  // main loops software-pipelined inside the wave (forward: operands by LDS-DMA; 1: through staging registers; 0: the round-1 loops, for A/B)
     // 4 waves per workgroup (one per SIMD) since the main loops are pipelined inside the wave: a wave no longer needs a
     // partner on its SIMD to fill its chunk-boundary gaps, and four partial tiles reduce faster than eight
     int fwd_nw = 4, dx_nw = 4, dw_tile = 1, dw_persist = 1, dwp_per_cu = 2, dw_merge = 1, loss_fuse = 1, tile_map = 0, stage_ahead = 1;  // dw_tile 0 = auto
@@ -486,22 +486,31 @@ static int run_forward(mlggd_engine *e, const Bunch &bn, int frames, bool traini
                 long long *st = stamps_for(e, KC_FWD, l, n_tiles * b_tiles);
 #define LAUNCH_FWD(NW, PIPE)                                                                                \
     {                                                                                                       \
-        const size_t lds = fwd_lds_floats<NW>() * sizeof(float);                                            \
+        const size_t lds = fwd_lds_floats<NW, PIPE>() * sizeof(float);                                      \
         CHK(ensure_lds(e, k_fwd<FWD_SIGMOID, NW, PIPE>, lds));                                              \
         launch_timed(e, k_fwd<FWD_SIGMOID, NW, PIPE>, dim3(n_tiles * b_tiles), dim3(64 * NW), lds, e->stream, fa, st); \
     }
-                // PIPE 1: main loop software-pipelined inside the wave (default); 0: the round-1 loop (A/B knob
-                // MLGGD_FWD_PIPE=0, and the 16-wave form, whose 128-VGPR budget the pipelined loop does not fit)
+                // PIPE 4 (default): main loop software-pipelined inside the wave, operands by LDS-DMA; 1: the same
+                // pipeline through staging registers (MLGGD_FWD_PIPE=1); 0: the round-1 loop (MLGGD_FWD_PIPE=0, and the
+                // 16-wave form, whose 128-VGPR budget and 160 KB of LDS the pipelined loops do not fit)
                 if (e->fwd_nw == 16) LAUNCH_FWD(16, 0)
+                else if (e->fwd_nw == 8 && e->fwd_pipe == 4) LAUNCH_FWD(8, 4)
                 else if (e->fwd_nw == 8 && e->fwd_pipe) LAUNCH_FWD(8, 1)
                 else if (e->fwd_nw == 8) LAUNCH_FWD(8, 0)
+                else if (e->fwd_pipe == 4) LAUNCH_FWD(4, 4)
                 else if (e->fwd_pipe) LAUNCH_FWD(4, 1)
                 else LAUNCH_FWD(4, 0)
 #undef LAUNCH_FWD
             } else {
-                const size_t lds = fwd_lds_floats<4>() * sizeof(float);
-                launch_timed(e, k_fwd<FWD_SLAB, 4>, dim3(n_tiles * b_tiles * e->S_out), dim3(256), lds, e->stream, fa,
-                             (long long *)nullptr);
+                const int nwg = n_tiles * b_tiles * e->S_out;
+                if (e->fwd_pipe == 4) {
+                    const size_t lds = fwd_lds_floats<4, 4>() * sizeof(float);
+                    CHK(ensure_lds(e, k_fwd<FWD_SLAB, 4, 4>, lds));
+                    launch_timed(e, k_fwd<FWD_SLAB, 4, 4>, dim3(nwg), dim3(256), lds, e->stream, fa, (long long *)nullptr);
+                } else {
+                    const size_t lds = fwd_lds_floats<4, 1>() * sizeof(float);
+                    launch_timed(e, k_fwd<FWD_SLAB, 4, 1>, dim3(nwg), dim3(256), lds, e->stream, fa, (long long *)nullptr);
+                }
             }
         }
         CHK(launch_check("k_fwd"));
@@ -1246,7 +1255,7 @@ int mlggd_create(const mlggd_config *cfg, const float *const *weights, const flo
     e->Dp = e->lsp[e->L - 1];
     if (const char *v = getenv("MLGGD_FWD_NW")) e->fwd_nw = atoi(v);
     if (const char *v = getenv("MLGGD_DX_NW")) e->dx_nw = atoi(v);
-    if (const char *v = getenv("MLGGD_FWD_PIPE")) e->fwd_pipe = atoi(v) ? 1 : 0;
+    if (const char *v = getenv("MLGGD_FWD_PIPE")) e->fwd_pipe = atoi(v);
     if (const char *v = getenv("MLGGD_DX_PIPE")) e->dx_pipe = atoi(v) ? 1 : 0;
     if (const char *v = getenv("MLGGD_DW_TILE")) e->dw_tile = atoi(v);
     if (const char *v = getenv("MLGGD_TWO_STREAMS")) e->two_streams = atoi(v);

@@ -116,7 +116,8 @@ struct FwdArgs {
     int b_shift, s_shift;  // log2 of b_tiles / S when they are powers of two, else -1 (divmod_by)
 };
 // LDS floats needed by fwd_body<.,NW>: staging/reduction tiles + the 32x33 transposition tile
-template <int NW> constexpr int fwd_lds_floats() { return NW * 2048 + 32 * 36; }
+// staging / reduction tiles (two 8 KB tiles per wave in the LDS-DMA form, PIPE 4; one otherwise) + the 32x36 transposition tile
+template <int NW, int PIPE> constexpr int fwd_lds_floats() { return NW * (PIPE == 4 ? 4096 : 2048) + 32 * 36; }
 
 template <int MODE, int NW, int PIPE = 1>
 __device__ __forceinline__ void fwd_body(const FwdArgs &A, const int bid, float *smem, long long *stamps) {
@@ -125,7 +126,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &A, const int bid, float 
     const int Kp = A.Kp, Np = A.Np, Bp = A.Bp, N = A.N, n_tiles = A.n_tiles, b_tiles = A.b_tiles, S = A.S;
     // per wave: [32 k rows][32] of W then [32 k rows][32] of Yt (8 KB); the cross-wave
     // reduction buffer red[NW][1024] aliases the same storage after the main loop
-    float(*tileT)[36] = reinterpret_cast<float(*)[36]>(smem + NW * 2048);
+    float(*tileT)[36] = reinterpret_cast<float(*)[36]>(smem + NW * (PIPE == 4 ? 4096 : 2048));
     stamp(stamps, 0, bid);
     stamp_clk(stamps, 4, bid);
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
@@ -177,6 +178,83 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &A, const int bid, float 
     const float bias_row = (MODE == FWD_SIGMOID && NW == 4) ? bias[n0 + (tid >> 3)] : 0.0f;  // 4-wave epilogue
     asm volatile("" ::: "memory");
 
+    if constexpr (PIPE == 4) {
+    // LDS-DMA form of the pipelined loop: a chunk goes global -> LDS directly (buffer_load ... lds, one wave-load = 8
+    // rows of 128 B = 1 KB of the row-major tile), no staging registers, no ds_write.  Two tiles per wave: while the
+    // MFMAs of chunk c run on registers, chunk c+2 is requested into the tile chunk c was read from (groups 0..3) and
+    // the fragments of chunk c+1 are read from the other tile (groups 4..7) behind a counted vmcnt that leaves the
+    // eight younger DMA instructions in flight.
+    float *t0 = smem + wave * 4096, *t1 = t0 + 2048;
+    const int endW = Kp * Np * 4, endY = Kp * Bp * 4;
+    float fa[16], fb[16], ga[16], gb[16];
+#define FWD_DMA1(T, C, Q)                                                          \
+    {                                                                              \
+        const int row0 = 2 * (p0 + 16 * (C));                                      \
+        const bool live = (C) < nch;                                               \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (__attribute__((address_space(3))) void *)(T + (Q) * 256), 16, voW, \
+                                                 live ? (row0 + 8 * (Q)) * Np * 4 : endW, 0, 0);        \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rY, (__attribute__((address_space(3))) void *)(T + 1024 + (Q) * 256), 16, voY, \
+                                                 live ? (row0 + 8 * (Q)) * Bp * 4 : endY, 0, 0);        \
+    }
+#define FWD_RD4(T, NA, NB, Q)                                                      \
+    {                                                                              \
+        _Pragma("unroll") for (int u = 4 * (Q); u < 4 * (Q) + 4; u++) {            \
+            NA[u] = (T)[h * 32 + i + u * 64];                                      \
+            NB[u] = (T)[1024 + h * 32 + i + u * 64];                               \
+        }                                                                          \
+    }
+    // chunk C on (FA, FB), read from tile TC one body ago; chunk C+1 is in tile TN (or landing); chunk C+2 -> TC
+#define FWD_BODYD(FA, FB, NA, NB, TC, TN, C)                                       \
+    {                                                                              \
+        __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0): the fragment reads of TC have returned */ \
+        _Pragma("unroll") for (int g = 0; g < 4; g++) {                            \
+            acc = mfma32(FA[2 * g], FB[2 * g], acc);                               \
+            acc = mfma32(FA[2 * g + 1], FB[2 * g + 1], acc);                       \
+            FWD_DMA1(TC, (C) + 2, g);                                              \
+            __builtin_amdgcn_sched_barrier(0);                                     \
+        }                                                                          \
+        __builtin_amdgcn_s_waitcnt(0x0F70 | 8); /* vmcnt(8): chunk C+1 has landed, chunk C+2 may be in flight */ \
+        _Pragma("unroll") for (int g = 4; g < 8; g++) {                            \
+            acc = mfma32(FA[2 * g], FB[2 * g], acc);                               \
+            acc = mfma32(FA[2 * g + 1], FB[2 * g + 1], acc);                       \
+            FWD_RD4(TN, NA, NB, g - 4);                                            \
+            __builtin_amdgcn_sched_barrier(0);                                     \
+        }                                                                          \
+    }
+#define FWD_DRAIND(FA, FB, CNT)                                                    \
+    {                                                                              \
+        _Pragma("unroll") for (int u = 0; u < 16; u++) {                           \
+            if (u < (CNT)) acc = mfma32(FA[u], FB[u], acc);                        \
+        }                                                                          \
+    }
+    if (nch > 0) {
+        const int nfull = npairs >> 4, rem = npairs & 15;
+#pragma unroll
+        for (int q = 0; q < 4; q++) FWD_DMA1(t0, 0, q);
+#pragma unroll
+        for (int q = 0; q < 4; q++) FWD_DMA1(t1, 1, q);
+        __builtin_amdgcn_s_waitcnt(0x0F70 | 8);
+#pragma unroll
+        for (int q = 0; q < 4; q++) FWD_RD4(t0, fa, fb, q);
+        __builtin_amdgcn_sched_barrier(0);
+        int c = 0;
+        for (; c + 1 < nfull; c += 2) {
+            FWD_BODYD(fa, fb, ga, gb, t0, t1, c);
+            FWD_BODYD(ga, gb, fa, fb, t1, t0, c + 1);
+        }
+        if (c < nfull) {
+            FWD_BODYD(fa, fb, ga, gb, t0, t1, c);
+            FWD_DRAIND(ga, gb, rem);
+        } else {
+            FWD_DRAIND(fa, fb, rem);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70 | 0);  // nothing may still be landing in LDS when the reduction reuses it
+    }
+#undef FWD_DMA1
+#undef FWD_RD4
+#undef FWD_BODYD
+#undef FWD_DRAIND
+    } else
     if constexpr (PIPE == 0) {
     float4 wa[4], ya[4], wb[4], yb[4];
     // rows past Kp are range-checked zeros; rows past this wave's range are only ever
