@@ -161,7 +161,7 @@ struct mlggd_engine {
     int fdim = 0, toff = 0, raw_frames = 0;
     unsigned step_counter = 0;
     // launch-plan knobs (defaults chosen from measurements; env overrides for A/B runs)
-    int fwd_pipe = 4, dx_pipe = 1;  // main loops software-pipelined inside the wave (forward: operands by LDS-DMA; 1: through staging registers; 0: the round-1 loops, for A/B)
+    int fwd_pipe = 4, dx_pipe = 4;  // main loops software-pipelined inside the wave (forward: operands by LDS-DMA; 1: through staging registers; 0: the round-1 loops, for A/B)
     // 4 waves per workgroup (one per SIMD) since the main loops are pipelined inside the wave: a wave no longer needs a
     // partner on its SIMD to fill its chunk-boundary gaps, and four partial tiles reduce faster than eight
     int fwd_nw = 4, dx_nw = 4, dw_tile = 1, dw_persist = 1, dwp_per_cu = 2, dw_merge = 1, loss_fuse = 1, tile_map = 0, stage_ahead = 1;  // dw_tile 0 = auto
@@ -960,13 +960,17 @@ static int run_dx(mlggd_engine *e, int l) {
     DxArgs xa = dx_args(e, l);
 #define LAUNCH_DX(NW, PIPE)                                                                                  \
     {                                                                                                        \
-        const size_t lds = dx_lds_floats<NW>() * sizeof(float);                                              \
+        const size_t lds = dx_lds_floats<NW, PIPE>() * sizeof(float);                                        \
         CHK(ensure_lds(e, k_dx<NW, PIPE>, lds));                                                             \
         launch_timed(e, k_dx<NW, PIPE>, dim3((Kp / 32) * b_tiles), dim3(64 * NW), lds, e->stream, xa, st);      \
     }
-    // PIPE 1: main loop software-pipelined inside the wave (default); 0: the round-1 loop (MLGGD_DX_PIPE=0, A/B)
+    // PIPE 4 (default where one workgroup per CU is all there is: <= 256 workgroups): main loop software-pipelined
+    // inside the wave, operands by LDS-DMA (136 KB of LDS); 1: the same pipeline through staging registers (71 KB: two
+    // workgroups per CU for larger minibatches; MLGGD_DX_PIPE=1); 0: the round-1 loop (MLGGD_DX_PIPE=0, A/B)
+    const bool dma = e->dx_pipe == 4 && (Kp / 32) * b_tiles <= 256;
     if (e->dx_nw == 8 && e->dx_pipe) LAUNCH_DX(8, 1)
     else if (e->dx_nw == 8) LAUNCH_DX(8, 0)
+    else if (dma) LAUNCH_DX(4, 4)
     else if (e->dx_pipe) LAUNCH_DX(4, 1)
     else LAUNCH_DX(4, 0)
 #undef LAUNCH_DX
@@ -1256,7 +1260,7 @@ int mlggd_create(const mlggd_config *cfg, const float *const *weights, const flo
     if (const char *v = getenv("MLGGD_FWD_NW")) e->fwd_nw = atoi(v);
     if (const char *v = getenv("MLGGD_DX_NW")) e->dx_nw = atoi(v);
     if (const char *v = getenv("MLGGD_FWD_PIPE")) e->fwd_pipe = atoi(v);
-    if (const char *v = getenv("MLGGD_DX_PIPE")) e->dx_pipe = atoi(v) ? 1 : 0;
+    if (const char *v = getenv("MLGGD_DX_PIPE")) e->dx_pipe = atoi(v);
     if (const char *v = getenv("MLGGD_DW_TILE")) e->dw_tile = atoi(v);
     if (const char *v = getenv("MLGGD_TWO_STREAMS")) e->two_streams = atoi(v);
     if (const char *v = getenv("MLGGD_DW_PERSIST")) e->dw_persist = atoi(v);

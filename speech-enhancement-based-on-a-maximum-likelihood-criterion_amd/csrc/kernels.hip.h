@@ -503,7 +503,8 @@ struct DxArgs {
     float *dEdXt_prev, *dEdX_prev;
     int Kp, Np, Bp, k_tiles, b_tiles, map, b_shift;
 };
-template <int NW> constexpr int dx_lds_floats() { return NW * (32 * DX_LDW + 2048) + 32 * 36; }
+// per wave: W piece [32][66] + dEdXt piece [64][32]; LDS-DMA form (PIPE 4): two sets of two unpadded 8 KB tiles
+template <int NW, int PIPE> constexpr int dx_lds_floats() { return NW * (PIPE == 4 ? 8192 : 32 * DX_LDW + 2048) + 32 * 36; }
 
 template <int NW, int PIPE = 1>
 __device__ __forceinline__ void dx_body(const DxArgs &A, const int bid, float *smem, long long *stamps) {
@@ -511,7 +512,7 @@ __device__ __forceinline__ void dx_body(const DxArgs &A, const int bid, float *s
     float *__restrict__ dEdXt_prev = A.dEdXt_prev, *__restrict__ dEdX_prev = A.dEdX_prev;
     const int Kp = A.Kp, Np = A.Np, Bp = A.Bp, k_tiles = A.k_tiles, b_tiles = A.b_tiles;
     // per wave: W piece [32][66] (2112 floats) + dEdXt piece [64 n][32] (2048 floats)
-    constexpr int WSZ = 32 * DX_LDW, STG = WSZ + 2048;
+    constexpr int WSZ = 32 * DX_LDW, STG = PIPE == 4 ? 8192 : WSZ + 2048;
     float(*tileT)[36] = reinterpret_cast<float(*)[36]>(smem + NW * STG);
     stamp(stamps, 0, bid);
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
@@ -569,6 +570,97 @@ __device__ __forceinline__ void dx_body(const DxArgs &A, const int bid, float *s
     }
     asm volatile("" ::: "memory");
 
+    if constexpr (PIPE == 4) {
+    // LDS-DMA form (see fwd_body): both pieces of a chunk go global -> LDS directly, into one of two tile sets.
+    // The dEdXt piece keeps its layout (a wave-load = 8 rows of 128 B; the row permutation moves into the per-lane
+    // global offset).  The W piece cannot keep the 66-float row stride -- a DMA writes lane-linear 16-byte slots --
+    // so its [32 k][16 quads] slots are filled with quad (q ^ (k & 15)) of row k: the global reads stay whole
+    // 256-byte row segments, and the 32 lanes of a transposed fragment read (one per row k, same quad) spread over
+    // the 16 slot columns instead of hitting one (a 2-way conflict is left: 16-byte slots, 8-byte reads).
+    float *ws0 = smem + wave * STG, *ds0 = ws0 + 2048, *ws1 = ws0 + 4096, *ds1 = ws0 + 6144;
+    const int endW = Kp * Np * 4, endD = Np * Bp * 4;
+    const int wr = lane >> 4, wq = lane & 15;  // W DMA: 4 rows x 16 slots per instruction
+    int voWd[4];
+#pragma unroll
+    for (int tt = 0; tt < 4; tt++) voWd[tt] = ((k0 + wr) * Np + 4 * (wq ^ (4 * tt + wr))) * 4;
+    const int voDd = (((r8 & ~3) | ((r8 & 1) << 1) | ((r8 >> 1) & 1)) * Bp + b0 + 4 * c4) * 4;
+    int aoff[16];  // fragment read offsets (floats) of this lane's row: quad j sits in slot j ^ (i & 15)
+#pragma unroll
+    for (int j = 0; j < 16; j++) aoff[j] = i * 64 + 4 * (j ^ (i & 15)) + 2 * h;
+    const int boff = h * 32 + i;
+    float fa[32], fb[32], ga[32], gb[32];
+#define DX_DMA1(WS, DS, C, T)                                                              \
+    {                                                                                      \
+        const int quad0 = q0 + (C)*16;                                                     \
+        const bool live = (C) < nch;                                                       \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (__attribute__((address_space(3))) void *)(WS + (T) * 256), 16, \
+                                                 voWd[(T) & 3], live ? quad0 * 16 + (T) * (16 * Np) : endW, 0, 0); \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rD, (__attribute__((address_space(3))) void *)(DS + (T) * 256), 16, \
+                                                 voDd, live ? (4 * quad0 + 8 * (T)) * Bp * 4 : endD, 0, 0); \
+    }
+#define DX_RD1(WS, DS, NA, NB, J)                                                          \
+    {                                                                                      \
+        NA[2 * (J)] = (WS)[aoff[J]];                                                       \
+        NA[2 * (J) + 1] = (WS)[aoff[J] + 1];                                               \
+        NB[2 * (J)] = (DS)[boff + (4 * (J)) * 32];                                         \
+        NB[2 * (J) + 1] = (DS)[boff + (4 * (J) + 2) * 32];                                 \
+    }
+    // chunk C on (FA, FB), read from set (WC, DC) one body ago; chunk C+1 is in / landing in set (WN, DN); C+2 -> (WC, DC)
+#define DX_BODYD(FA, FB, NA, NB, WC, DC, WN, DN, C)                                        \
+    {                                                                                      \
+        __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0): the fragment reads of (WC, DC) have returned */ \
+        _Pragma("unroll") for (int g = 0; g < 8; g++) {                                    \
+            acc = mfma32(FA[2 * g], FB[2 * g], acc);                                       \
+            acc = mfma32(FA[2 * g + 1], FB[2 * g + 1], acc);                               \
+            DX_DMA1(WC, DC, (C) + 2, g);                                                   \
+            __builtin_amdgcn_sched_barrier(0);                                             \
+        }                                                                                  \
+        __builtin_amdgcn_s_waitcnt(0x4F70); /* vmcnt(16): chunk C+1 has landed, the 16 loads of C+2 may be in flight */ \
+        _Pragma("unroll") for (int g = 8; g < 16; g++) {                                   \
+            acc = mfma32(FA[2 * g], FB[2 * g], acc);                                       \
+            acc = mfma32(FA[2 * g + 1], FB[2 * g + 1], acc);                               \
+            DX_RD1(WN, DN, NA, NB, 2 * (g - 8));                                           \
+            DX_RD1(WN, DN, NA, NB, 2 * (g - 8) + 1);                                       \
+            __builtin_amdgcn_sched_barrier(0);                                             \
+        }                                                                                  \
+    }
+#define DX_DRAIND(FA, FB, CNT)                                                             \
+    {                                                                                      \
+        _Pragma("unroll") for (int j = 0; j < 16; j++) {                                   \
+            if (j < (CNT)) {                                                               \
+                acc = mfma32(FA[2 * j], FB[2 * j], acc);                                   \
+                acc = mfma32(FA[2 * j + 1], FB[2 * j + 1], acc);                           \
+            }                                                                              \
+        }                                                                                  \
+    }
+    if (nch > 0) {
+        const int nfull = myq >> 4, rem = myq & 15;
+#pragma unroll
+        for (int t = 0; t < 8; t++) DX_DMA1(ws0, ds0, 0, t);
+#pragma unroll
+        for (int t = 0; t < 8; t++) DX_DMA1(ws1, ds1, 1, t);
+        __builtin_amdgcn_s_waitcnt(0x4F70);  // vmcnt(16)
+#pragma unroll
+        for (int j = 0; j < 16; j++) DX_RD1(ws0, ds0, fa, fb, j);
+        __builtin_amdgcn_sched_barrier(0);
+        int c = 0;
+        for (; c + 1 < nfull; c += 2) {
+            DX_BODYD(fa, fb, ga, gb, ws0, ds0, ws1, ds1, c);
+            DX_BODYD(ga, gb, fa, fb, ws1, ds1, ws0, ds0, c + 1);
+        }
+        if (c < nfull) {
+            DX_BODYD(fa, fb, ga, gb, ws0, ds0, ws1, ds1, c);
+            DX_DRAIND(ga, gb, rem);
+        } else {
+            DX_DRAIND(fa, fb, rem);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): nothing may still be landing when the reduction reuses the LDS
+    }
+#undef DX_DMA1
+#undef DX_RD1
+#undef DX_BODYD
+#undef DX_DRAIND
+    } else
     if constexpr (PIPE == 0) {
     float4 wa[8], da[8], wv[8], dv[8];
     // Quads past this wave's range read valid or range-checked-zero data and are only ever

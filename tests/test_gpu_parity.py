@@ -117,7 +117,7 @@ def test_largest_advertised_bunch_with_the_ml_loss(pkg, pyoracle, synth):
 
 def test_forward_and_dx_loop_variants(pkg, pyoracle, synth, monkeypatch):
     """The forward / dX main loops exist in several forms (software-pipelined inside the wave = default, forward with
-    its operands by LDS-DMA or, MLGGD_FWD_PIPE=1, through staging registers; the round-1 loops behind
+    the operands by LDS-DMA or, MLGGD_FWD_PIPE=1 / MLGGD_DX_PIPE=1, through staging registers; the round-1 loops behind
     MLGGD_FWD_PIPE=0 / MLGGD_DX_PIPE=0) and for 4 (default) or 8 waves per workgroup.  The pipelined loop
     issues the same MFMAs in the same order: bit-identical weights for the same wave count.  Another wave count is
     another K split (summation order): equal to rounding, and each within the oracle bound.  Layer widths chosen so
@@ -147,7 +147,7 @@ def test_forward_and_dx_loop_variants(pkg, pyoracle, synth, monkeypatch):
     for nw in ("4", "8"):
         waves = {"MLGGD_FWD_NW": nw, "MLGGD_DX_NW": nw}
         new_loop, old_loop = run(waves), run(dict(waves, **old))
-        staged = run(dict(waves, MLGGD_FWD_PIPE="1"))  # the pipelined forward loop through staging registers
+        staged = run(dict(waves, MLGGD_FWD_PIPE="1", MLGGD_DX_PIPE="1"))  # the pipelined loops through staging registers
         for x, y, z in zip(new_loop, old_loop, staged):
             assert np.array_equal(x, y) and np.array_equal(x, z), nw
         for x, y in zip(new_loop, wo + bo):
