@@ -2,31 +2,42 @@
 """bench.py -- training frames/s of the ML-GGD DNN trainer hot path on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is one pass of the hot path (BP_GPU::train_bunch_single, BP_GPU.cu:308-440) over one
-128-frame minibatch per GPU of synthetic 257x11 -> 2048x3 -> 257 data already resident in HBM.
-Prints ONE JSON line (rank 0).  N>1 is data parallel (weak scaling: 128 frames per GPU; the exchange runs
-over RCCL inside libmlggd.so -- by default an all-gather of the gradient's factors, with the update replicated
-up to 5 ranks and sharded from 6; MLGGD_DP_MODE=allreduce selects the all-reduce of
-the weight gradients); torch.distributed is only used for the rendezvous, the barriers and the max-over-ranks
-of the wall time.
+N > 1 needs no launcher: when WORLD_SIZE is not set, this process starts N child ranks itself -- BEFORE it imports
+torch or touches a GPU -- (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment), relays rank
+0's JSON line and exits with the children's status.  The torchrun form works too
+(python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...):
+with WORLD_SIZE set this process is simply one rank.
 
-`loss_vs_oracle` (and `ml_ggd.loss_vs_oracle`) is BASELINE.json's "loss-vs-ref delta": relative difference of the CV
-numbers the reference logs (BPtrain.cc:131-138) between this engine and the CPU oracle after the same steps.
+A "step" is one pass of the hot path (BP_GPU::train_bunch_single, BP_GPU.cu:308-440) over one 128-frame minibatch
+per GPU of synthetic 257x11 -> 2048x3 -> 257 data already resident in HBM.  Prints ONE JSON line (rank 0).
+N > 1 is data parallel (weak scaling: 128 frames per GPU; the exchange runs over RCCL inside libmlggd.so -- by default
+an all-gather of the gradient's factors with the update replicated up to 5 ranks and sharded from 6, DESIGN.md
+section 6; `--dp-mode allreduce` / MLGGD_DP_MODE=allreduce selects BASELINE.json's all-reduce of the weight
+gradients, which is also measured as `dp_arms.allreduce` in the same invocation).  torch.distributed is used over
+GLOO only -- rendezvous, barriers, max over ranks; the only RCCL communicator is the engine's own.
 
-The timed region contains nothing but the K steps.  The `roofline` object comes from an UNTIMED post-pass of
-64 further steps in which every launch of the dominant kernel carries a HIP start/stop event pair on the engine's
-stream (hipExtLaunchKernelGGL: the dispatch's own begin/end timestamps, comparable with rocprofv3's average); `ml_ggd` is BASELINE.json configs[2] (MLflag=1, beta=1.2) measured the same way in the same invocation.
+Timing: `ms_per_step` is the MEDIAN over `--windows` (default 9) back-to-back windows of exactly --steps steps each;
+a window is [barrier + device sync] t0 [K steps] [device sync] t1 on every rank, its time the MAX over ranks of
+t1 - t0 (no collective and no event inside a window).  `window_ms_min/max` give the spread.
+
+`loss_vs_oracle` (and `ml_ggd.loss_vs_oracle`, `ml_ggd_beta0.9.loss_vs_oracle`) is BASELINE.json's "loss-vs-ref delta":
+relative difference of the CV numbers the reference logs (BPtrain.cc:131-138) between this engine and the CPU oracle
+after the same steps.  The `roofline` object comes from an UNTIMED post-pass of 64 further steps in which every
+launch of the dominant kernel carries a HIP start/stop event pair on the engine's stream (hipExtLaunchKernelGGL: the
+dispatch's own begin/end timestamps, comparable with rocprofv3's average); `ml_ggd` is BASELINE.json configs[2]
+(MLflag=1, beta=1.2) measured the same way in the same invocation.  `dp_breakdown` (untimed post-passes, one per
+kernel class): device time of the rank's own kernels per step against the step's wall time -- the difference is the
+exposed part of the exchange.
 """
 import argparse
-import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -35,55 +46,221 @@ PKG = "speech-enhancement-based-on-a-maximum-likelihood-criterion_amd"
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X fp32 matrix peak, MI355X_MICROARCH.md "Chip-level parameters"
 HBM_PEAK_GBPS = 8000.0        # HBM3E peak (spec), same table
 
+DP_EXCHANGE = {0: None, 1: "all-reduce of weight gradients (RCCL)",
+               2: "all-gather of the gradient factors Y, dEdX (RCCL); every rank forms the global gradient",
+               3: "all-gather of the gradient factors Y, dEdX; each rank updates its block of weight rows; all-gather of W"}
+DP_MODE_NAME = {0: None, 1: "allreduce", 2: "gather", 3: "shard"}
+
 
 def flop_per_frame(ls):
     P = sum(ls[i] * ls[i + 1] for i in range(len(ls) - 1))
     return 2 * P + 2 * P + 2 * (P - ls[0] * ls[1])  # fwd + dW + dX (no dX for layer 1)
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--windows", type=int, default=9, help="timed windows of --steps steps each; the median is reported")
     ap.add_argument("--loss", choices=["mmse", "ml"], default="mmse",
                     help="mmse = BASELINE.json configs[1] (MLflag=0, beta=2); ml = configs[2] (MLflag=1, beta=1.2)")
     ap.add_argument("--bunch", type=int, default=128)
     ap.add_argument("--hidden", type=int, default=2048)
     ap.add_argument("--nhid", type=int, default=3)
+    ap.add_argument("--dp-mode", choices=["auto", "allreduce", "gather", "shard"], default="auto",
+                    help="gradient exchange of the headline number for N > 1 (auto: engine default, DESIGN.md section 6)")
+    ap.add_argument("--no-dp-arms", action="store_true", help="N > 1: do not also measure the other exchange modes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-ml", action="store_true", help="skip the ml_ggd (configs[2]) measurement")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    args = ap.parse_args()
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="start the ranks, rendezvous over gloo, report rank/world and exit before touching a GPU")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="self-launcher: seconds before the ranks are killed")
+    return ap.parse_args(argv)
 
+
+# ----------------------------------------------------------------------------------------------------------------
+# self-launcher: N child ranks, started before anything in this process touches a GPU (it never does)
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args, argv):
+    n = args.gpus
+    env0 = dict(os.environ)
+    env0.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port()), "WORLD_SIZE": str(n),
+                 "LOCAL_WORLD_SIZE": str(n), "MLGGD_BENCH_LAUNCHED": "1"})
+    env0.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this host driver
+    env0.setdefault("OMP_NUM_THREADS", "4")
+    procs = []
+    for r in range(n):
+        env = dict(env0, RANK=str(r), LOCAL_RANK=str(r))
+        # rank 0's stdout is the JSON line (relayed below); the other ranks' stdout joins stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+
+    def relay():
+        for line in procs[0].stdout:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+
+    t = threading.Thread(target=relay, daemon=True)
+    t.start()
+    deadline = time.time() + args.launch_timeout
+    first_bad, grace = None, None
+    while True:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            break
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad and first_bad is None:
+            # the peers' own watchdogs get a chance to say where they were
+            first_bad, grace = bad[0], time.time() + float(os.environ.get("MLGGD_BENCH_GRACE_S", "20"))
+        now = time.time()
+        if (grace is not None and now > grace) or now > deadline:
+            why = ("rank %d exited with status %d" % first_bad) if first_bad else ("no result after %.0f s" % args.launch_timeout)
+            sys.stderr.write("bench launcher: %s; stopping the remaining ranks\n" % why)
+            for p in procs:  # exactly the processes started above
+                if p.poll() is None:
+                    p.kill()
+            break
+        time.sleep(0.1)
+    for p in procs:
+        p.wait()
+    t.join(timeout=5)
+    codes = [p.returncode for p in procs]
+    if any(codes):
+        sys.stderr.write("bench launcher: rank exit codes %s\n" % codes)
+    return next((c for c in codes if c), 0) if first_bad is None else first_bad[1]
+
+
+# ----------------------------------------------------------------------------------------------------------------
+class Watchdog:
+    """A rank that sits in one phase longer than that phase's budget says where it was and ends the process (status 3)
+    instead of leaving its peers -- and the driver -- blocked in a collective until an outer time limit."""
+
+    def __init__(self, rank, world):
+        self.rank, self.world = rank, world
+        self.phase, self.detail, self.deadline, self.t_enter = "start", "", None, time.time()
+        self.on_fire = None  # rank 0: print what has already been measured
+        self.scale = float(os.environ.get("MLGGD_BENCH_WATCHDOG_SCALE", "1"))
+        threading.Thread(target=self._run, daemon=True).start()
+
+    def enter(self, phase, seconds, detail=""):
+        self.phase, self.detail, self.t_enter = phase, detail, time.time()
+        self.deadline = self.t_enter + seconds * self.scale if seconds else None
+
+    def _run(self):
+        while True:
+            time.sleep(0.25)
+            d = self.deadline
+            if d is not None and time.time() > d:
+                sys.stderr.write("bench watchdog: rank %d of %d stuck in phase '%s' for %.0f s (%s); giving up\n"
+                                 % (self.rank, self.world, self.phase, time.time() - self.t_enter,
+                                    self.detail or "no collective in flight"))
+                sys.stderr.flush()
+                rc = 3
+                if self.on_fire is not None:
+                    try:
+                        rc = self.on_fire(self.phase)
+                    except Exception as ex:  # noqa: BLE001 -- last words only
+                        sys.stderr.write("bench watchdog: %r\n" % (ex,))
+                sys.stdout.flush()
+                os._exit(rc)
+
+
+def dry_launch(rank, world, local_rank):
+    """Rendezvous only: proves the launch path (children, env, gloo) without a GPU."""
+    import datetime
     import torch
     import torch.distributed as dist
+    wd = Watchdog(rank, world)
+    # test hooks for tests/test_bench_launcher.py: a rank that dies early / a rank that never arrives
+    if os.environ.get("MLGGD_BENCH_TEST_FAIL_RANK") == str(rank):
+        sys.stderr.write("rank %d: failing on request\n" % rank)
+        return 7
+    if os.environ.get("MLGGD_BENCH_TEST_HANG_RANK") == str(rank):
+        wd.enter("test hang", 60, "nothing: this rank never joins the rendezvous")
+        time.sleep(3600)
+    wd.enter("gloo rendezvous", 120, "init_process_group(gloo)")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=120))
+        t = torch.tensor([float(rank)], dtype=torch.float64)
+        wd.enter("gloo all_reduce", 60, "all_reduce(sum of ranks)")
+        dist.all_reduce(t)
+        got = [None] * world
+        dist.all_gather_object(got, {"rank": rank, "local_rank": local_rank, "pid": os.getpid()})
+        assert t.item() == world * (world - 1) / 2, t
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        got = [{"rank": 0, "local_rank": local_rank, "pid": os.getpid()}]
+    if rank == 0:
+        print(json.dumps({"dry_launch": True, "world": world, "backend": "gloo" if world > 1 else None,
+                          "ranks": sorted(g["rank"] for g in got), "local_ranks": sorted(g["local_rank"] for g in got),
+                          "distinct_pids": len({g["pid"] for g in got}),
+                          "launched_by": "bench.py" if os.environ.get("MLGGD_BENCH_LAUNCHED") else
+                                         ("external launcher" if world > 1 else "direct"),
+                          "gpu_touched": False}), flush=True)
+    return 0
+
+
+# ----------------------------------------------------------------------------------------------------------------
+def rank_main(args):
+    import datetime
+    import importlib
+
+    import numpy as np
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
         args.gpus = world
+    if args.dry_launch:
+        return dry_launch(rank, world, local_rank)
+
+    import torch
+    import torch.distributed as dist
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("rank %d: LOCAL_RANK %d but only %d GPU(s) visible" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
+    wd = Watchdog(rank, world)
 
     pkg = importlib.import_module(PKG)
     synth = importlib.import_module(PKG + ".synth")
     pkg.load()
 
+    last_coll = {"what": ""}
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        wd.enter("gloo rendezvous", 300, "init_process_group(gloo)")
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=600))
 
-    def barrier():
+    def barrier(what="barrier"):
         torch.cuda.synchronize()
         if world > 1:
+            last_coll["what"] = "gloo " + what
             dist.barrier()
         torch.cuda.synchronize()
+
+    def max_over_ranks(vals):
+        if world == 1:
+            return list(vals)
+        t = torch.tensor(list(vals), dtype=torch.float64)
+        last_coll["what"] = "gloo all_reduce(max)"
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(x) for x in t]
 
     B = args.bunch
     ls = synth.baseline_layersizes(hidden=args.hidden, nhid=args.nhid)
@@ -91,15 +268,28 @@ def main():
     ws, bs = synth.make_weights(ls)  # same weights on every rank
     nb = min(max(args.steps, args.warmup, 1), 64)  # resident bunches, cycled
     inp, targ = synth.make_frames(nb * B, 257, 11, seed=synth.DEFAULT_SEED + 1 + rank)
+    fpf = flop_per_frame(ls)
+    frames = args.steps * B * world
 
-    eng = pkg.BPGpu(synth.DEFAULT_SEED, local_rank, ls, B, 0.1, 0.9, 1e-5, ws, bs, beta, ml)
-    if world > 1:
-        uid = [pkg.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        eng.comm_init(uid[0], world, rank)
-    eng.load_chunk(inp, targ)
+    def make_engine(ml_, beta_, dp_mode):
+        """An engine on this rank's GPU with the chunk resident; N > 1: joined to a fresh RCCL communicator."""
+        if dp_mode and dp_mode != "auto":
+            os.environ["MLGGD_DP_MODE"] = dp_mode
+        elif "MLGGD_DP_MODE_USER" in os.environ:
+            os.environ["MLGGD_DP_MODE"] = os.environ["MLGGD_DP_MODE_USER"]
+        else:
+            os.environ.pop("MLGGD_DP_MODE", None)
+        wd.enter("engine create", 300)
+        eng = pkg.BPGpu(synth.DEFAULT_SEED, local_rank, ls, B, 0.1, 0.9, 1e-5, ws, bs, beta_, ml_)
+        if world > 1:
+            wd.enter("RCCL communicator init (%s)" % (dp_mode or "auto"), 600, "gloo broadcast of the id, then ncclCommInitRank")
+            uid = [pkg.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            eng.comm_init(uid[0], world, rank)
+        eng.load_chunk(inp, targ)
+        return eng
 
-    def run_steps(k):
+    def run_steps(eng, k):
         done = 0
         while done < k:
             m = min(k - done, nb)
@@ -107,30 +297,61 @@ def main():
             assert got == m
             done += m
 
-    # clock / power-state ramp: the GPU needs tens of milliseconds under load to reach its steady clocks, a
-    # short --warmup does not get there (100 timed steps after 10 warm-up steps read 8 % low).  Untimed.
-    # A fixed step count, not a time: data-parallel ranks must all run the same number of steps.
-    run_steps(512)
-    eng.sync()
-    run_steps(args.warmup)
-    eng.sync()
-    def timed(engine_steps, k):
-        barrier()
-        t0 = time.perf_counter()
-        engine_steps(k)
-        barrier()
-        d = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([d], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            d = float(t.item())
-        return d
-
-    def steps_and_sync(k):
-        run_steps(k)
+    def measure(eng, label, ramp):
+        """Median over args.windows windows of exactly args.steps steps (module docstring)."""
+        # clock / power-state ramp: the GPU needs tens of milliseconds under load to reach its steady clocks, a short
+        # --warmup does not get there (100 timed steps after 10 warm-up steps read 8 % low).  Untimed.  A fixed step
+        # count, not a time: data-parallel ranks must all run the same number of steps.
+        wd.enter("%s: ramp + warm-up" % label, 300, "RCCL collectives of the training steps")
+        run_steps(eng, ramp)
         eng.sync()
+        run_steps(eng, args.warmup)
+        eng.sync()
+        wins = []
+        for w in range(max(1, args.windows)):
+            wd.enter("%s: timed window %d" % (label, w), 180, "RCCL collectives of the training steps / gloo barrier")
+            barrier("barrier before window %d" % w)
+            t0 = time.perf_counter()
+            run_steps(eng, args.steps)
+            eng.sync()
+            wins.append(time.perf_counter() - t0)
+        wd.enter("%s: max over ranks" % label, 120, "gloo all_reduce(max)")
+        wins = max_over_ranks(wins)
+        srt = sorted(wins)
+        med = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
+        return {"dt": med, "value": frames / med, "ms_per_step": med / args.steps * 1e3,
+                "window_ms": [round(x * 1e3, 4) for x in wins]}
 
-    dt = timed(steps_and_sync, args.steps)
+    def class_times(eng, label, steps=32):
+        """Device time of this rank's own kernels per step, by kernel class (untimed post-passes)."""
+        out = {}
+        for cls in ("transpose", "fwd", "loss", "dx", "dw", "update"):
+            wd.enter("%s: kernel-class pass '%s'" % (label, cls), 180, "RCCL collectives of the training steps")
+            eng.profile_select(cls, 0, steps * 2 * (len(ls) + 1), stride=1)
+            run_steps(eng, steps)
+            eng.sync()
+            us, n = eng.profile_read()
+            eng.profile_select(None)
+            out[cls] = us * n / steps
+        return out
+
+    out = {}
+    state = {"headline_done": False}
+
+    def last_words(phase):
+        # rank 0, watchdog fired: if the headline was already measured (a secondary measurement got stuck), still
+        # deliver it -- with the reason -- and report success for THAT; otherwise nothing to print, status 3
+        if rank == 0 and state["headline_done"]:
+            out["incomplete"] = "watchdog: stuck in phase '%s' (%s)" % (phase, last_coll["what"])
+            print(json.dumps(out), flush=True)
+            return 0
+        return 0 if state["headline_done"] else 3
+
+    wd.on_fire = last_words
+
+    eng = make_engine(ml, beta, args.dp_mode)
+    mode = eng.dp_mode()
+    head = measure(eng, "headline", 512)
 
     roofline = None
     if not args.no_kernel_timing:
@@ -139,8 +360,9 @@ def main():
         # the dispatch's own begin / end timestamps -- the quantity rocprofv3 --kernel-trace reports -- and no
         # bracket cost has to be calibrated away
         post = 64
+        wd.enter("roofline post-pass", 180, "RCCL collectives of the training steps")
         eng.profile_select("dw", 0, post * (len(ls) - 1), stride=1)
-        run_steps(post)
+        run_steps(eng, post)
         eng.sync()
         us_raw, nlaunch = eng.profile_read()
         eng.profile_select(None)
@@ -152,7 +374,7 @@ def main():
         by = eng.kernel_work("dw", 0)[1] / nl
         if nlaunch > 0 and us > 0:
             ach = fl / (us * 1e-6) / 1e12
-            traffic = None
+            traffic, traffic_source = None, None
             pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             # HBM bytes per launch from rocprofv3 --pmc runs (profiles/README.md); they were collected on
             # the single-GPU plan (one launch for all layers, default shape) and only describe that one
@@ -160,17 +382,18 @@ def main():
             if os.path.exists(pmc) and world == 1 and nl == 1 and default_shape:
                 try:
                     traffic = json.load(open(pmc)).get("k_dw", {}).get("hbm_bytes_per_launch")
+                    traffic_source = ("profiles/pmc_traffic.json (committed; separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                      "passes of this workload, not measured in this run)")
                 except Exception:
                     traffic = None
             # which roof binds this kernel: arithmetic intensity against the machine balance
             # 157.3 TFLOP/s / 8 TB/s = 19.7 FLOP/B (at B = 128 the kernel moves 16 B per 2*B flops -> HBM)
             gbps = by / (us * 1e-6) / 1e9
-            mode = eng.dp_mode() if world > 1 else 0  # 2, 3: the fused kernel runs over the gathered minibatch
             units = max(1, ((B + 31) // 32 * 32) * (world if mode >= 2 else 1) // 64)
             n_glob = B * world
             name = "k_dwp<%d,%s,%s> (persistent dW GEMM + fused momentum/weight-decay/bias update, %s%s)" % (
                 units, "true" if mode != 1 else "false", "true" if n_glob & (n_glob - 1) == 0 else "false",
-                "all layers in one launch" if nl == 1 else "one launch per layer",
+                "all layers in one launch" if nl == 1 else "%d launches per step" % nl,
                 {0: "", 1: "", 2: ", over the %d gathered frames of all ranks" % (B * world),
                  3: ", this rank's block of weight rows over the %d gathered frames of all ranks" % (B * world)}[mode])
             if fl / by < MFMA_F32_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBPS * 1e9):
@@ -179,18 +402,26 @@ def main():
             else:
                 roofline = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS,
                             "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic}
-            roofline.update({"mean_launch_us": round(us, 2), "launches_timed": nlaunch,
+            roofline.update({"traffic_source": traffic_source, "mean_launch_us": round(us, 2), "launches_timed": nlaunch,
                              "timing": "hipExtLaunchKernelGGL start/stop events per launch, untimed post-pass of %d steps" % post,
                              "algorithmic_flops_per_launch": fl, "algorithmic_bytes_per_launch": by,
                              "algorithmic_TFLOPs": round(ach, 2), "algorithmic_GBps": round(gbps, 1)})
 
-    frames = args.steps * B * world
-    value = frames / dt
-    fpf = flop_per_frame(ls)
-    out = {
+    def breakdown(eng_, step_ms, label):
+        ct = class_times(eng_, label)
+        comp = sum(ct.values())
+        return {"step_us": round(step_ms * 1e3, 2), "compute_us": round(comp, 2),
+                "compute_us_by_class": {k: round(v, 2) for k, v in ct.items()},
+                "exposed_exchange_us": round(step_ms * 1e3 - comp, 2),
+                "note": "compute = device time of this rank's own kernels per step (GEMM classes: the dispatches' own "
+                        "begin/end timestamps; transpose / loss / update: event brackets, which add ~2 us each and, "
+                        "data parallel, include the wait for the 257-float all-reduce inside the loss bracket); "
+                        "exposed = step wall time - compute; rank 0's view"}
+
+    out.update({
         "metric": "training frames/sec (%d-frame minibatch)" % B,
-        "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 5),
+        "value": round(head["value"], 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(head["ms_per_step"], 5),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": "%s-%s sigmoid DNN, %s, %d-frame minibatch per GPU, synthetic pfile-shaped frames"
@@ -198,31 +429,61 @@ def main():
                       "ML-GGD loss (MLflag=1, beta=1.2)" if ml else "MMSE loss (MLflag=0, beta=2)", B),
                    "layersizes": ls, "bunchsize_per_gpu": B, "global_minibatch": B * world,
                    "parallelism": "dp%d" % world, "flop_per_frame": fpf,
-                   "dp_exchange": {0: None, 1: "all-reduce of weight gradients (RCCL)",
-                                   2: "all-gather of the gradient factors Y, dEdX (RCCL); every rank forms the global gradient",
-                                   3: "all-gather of the gradient factors Y, dEdX; each rank updates its block of weight rows; all-gather of W"}[eng.dp_mode()]},
-        "step_roofline_frac": round(value * fpf / (world * MFMA_F32_PEAK_TFLOPS * 1e12), 4),
+                   "dp_exchange": DP_EXCHANGE[mode], "dp_mode": DP_MODE_NAME[mode]},
+        "timing": {"windows": len(head["window_ms"]), "statistic": "median of the windows' max-over-ranks times",
+                   "window_ms": head["window_ms"], "window_ms_min": min(head["window_ms"]),
+                   "window_ms_max": max(head["window_ms"]),
+                   "window": "[gloo barrier + device sync] t0 [--steps steps] [device sync] t1; nothing else inside"},
+        "step_roofline_frac": round(head["value"] * fpf / (world * MFMA_F32_PEAK_TFLOPS * 1e12), 4),
         "roofline": roofline,
-    }
+        "rccl_ranks": eng.comm_info()[0] if world > 1 else 0,
+        "rendezvous": "gloo" if world > 1 else None,
+        "launched_by": "bench.py (child ranks)" if os.environ.get("MLGGD_BENCH_LAUNCHED") else
+                       ("external launcher" if world > 1 else "direct"),
+    })
+    state["headline_done"] = True
+    if not args.no_kernel_timing:
+        out["dp_breakdown"] = breakdown(eng, head["ms_per_step"], "headline")
 
     if args.loss == "mmse" and not args.no_ml:
         # BASELINE.json configs[2] in the same invocation: ML-GGD loss (MLflag=1, beta=1.2), same data, same steps
         eng.close()
-        eng = pkg.BPGpu(synth.DEFAULT_SEED, local_rank, ls, B, 0.1, 0.9, 1e-5, ws, bs, 1.2, 1)
-        if world > 1:
-            uid = [pkg.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0)
-            eng.comm_init(uid[0], world, rank)
-        eng.load_chunk(inp, targ)
-        run_steps(256)
-        run_steps(args.warmup)
-        eng.sync()
-        dt_ml = timed(steps_and_sync, args.steps)
+        eng = make_engine(1, 1.2, args.dp_mode)
+        m_ml = measure(eng, "ml_ggd", 256)
         out["ml_ggd"] = {"workload": "the same net and data with the ML-GGD loss (MLflag=1, beta=1.2): BASELINE.json configs[2]",
-                         "value": round(frames / dt_ml, 1), "unit": "frames/s", "ms_per_step": round(dt_ml / args.steps * 1e3, 5),
-                         "step_roofline_frac": round(frames / dt_ml * fpf / (world * MFMA_F32_PEAK_TFLOPS * 1e12), 4)}
+                         "value": round(m_ml["value"], 1), "unit": "frames/s", "ms_per_step": round(m_ml["ms_per_step"], 5),
+                         "window_ms_min": min(m_ml["window_ms"]), "window_ms_max": max(m_ml["window_ms"]),
+                         "step_roofline_frac": round(m_ml["value"] * fpf / (world * MFMA_F32_PEAK_TFLOPS * 1e12), 4)}
+        if world > 1 and not args.no_kernel_timing:
+            out["ml_ggd"]["dp_breakdown"] = breakdown(eng, m_ml["ms_per_step"], "ml_ggd")
+
+    if world > 1 and not args.no_dp_arms:
+        # The other gradient exchanges on the same ranks, same data, same windows: BASELINE.json names the all-reduce of
+        # the weight gradients; the engine's default is the factor all-gather.  Every arm the
+        # shape allows is reported so that one multi-GPU run decides the default from a measurement.
+        arms = {}
+        eng.close()
+        eng = None
+        for arm in ("allreduce", "gather", "shard"):
+            if arm == DP_MODE_NAME[mode]:
+                arms[arm] = {"value": out["value"], "ms_per_step": out["ms_per_step"], "same_as": "headline"}
+                continue
+            try:
+                e2 = make_engine(ml, beta, arm)
+            except pkg.MlggdError as ex:  # the shape rules the factor exchange out (every rank takes this branch)
+                arms[arm] = {"unavailable": str(ex)[:160]}
+                continue
+            m2 = measure(e2, "dp arm " + arm, 256)
+            arms[arm] = {"value": round(m2["value"], 1), "unit": "frames/s", "ms_per_step": round(m2["ms_per_step"], 5),
+                         "window_ms_min": min(m2["window_ms"]), "window_ms_max": max(m2["window_ms"]),
+                         "dp_exchange": DP_EXCHANGE[e2.dp_mode()]}
+            if not args.no_kernel_timing:
+                arms[arm]["dp_breakdown"] = breakdown(e2, m2["ms_per_step"], "dp arm " + arm)
+            e2.close()
+        out["dp_arms"] = arms
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        wd.enter("cpu baseline + loss_vs_oracle", 900)
         from oracle import pyoracle  # CPU oracle = the checker, timed here only as the reported CPU baseline
         ora = pyoracle.OracleNet(ls, B, 0.1, 0.9, 1e-5, beta, ml, ws, bs)
         ora.train_bunch(inp[:B], targ[:B])
@@ -236,7 +497,7 @@ def main():
         cdt = time.perf_counter() - t1
         out["cpu_baseline"] = {"value": round(n * B / cdt, 1), "unit": "frames/s", "cores": pyoracle.num_threads(),
                                "kind": "port", "sample": "%d steps over the same %d-frame minibatches (oracle, OpenMP, threads = usable CPU share)"
-                               % (n, B), "gpu_over_cpu": round(value / (n * B / cdt), 1)}
+                               % (n, B), "gpu_over_cpu": round(head["value"] / (n * B / cdt), 1)}
 
         # BASELINE.json's "loss-vs-ref delta": a fresh engine trains exactly the steps the oracle has just been timed
         # on (the oracle here is the CHECKER; nothing below is timed), then both score a held-out synthetic chunk with
@@ -263,23 +524,48 @@ def main():
             chk.close()
             return {k: (v if k == "steps" else float("%.2e" % v)) for k, v in d.items()}
 
+        def oracle_after(ml_, beta_, n_):
+            o = pyoracle.OracleNet(ls, B, 0.1, 0.9, 1e-5, beta_, ml_, ws, bs)
+            o.train_bunch(inp[:B], targ[:B])
+            o.train_bunch(inp[:B], targ[:B])
+            for i in range(n_):
+                o.train_bunch(inp[(i % nb) * B:(i % nb + 1) * B], targ[(i % nb) * B:(i % nb + 1) * B])
+            return o
+
         out["loss_vs_oracle"] = loss_delta(ml, beta, ora, n)
         ora.close()
         if "ml_ggd" in out:
             n_ml = min(n, 150)
-            ora = pyoracle.OracleNet(ls, B, 0.1, 0.9, 1e-5, 1.2, 1, ws, bs)
-            ora.train_bunch(inp[:B], targ[:B])
-            ora.train_bunch(inp[:B], targ[:B])
-            for i in range(n_ml):
-                ora.train_bunch(inp[(i % nb) * B:(i % nb + 1) * B], targ[(i % nb) * B:(i % nb + 1) * B])
+            ora = oracle_after(1, 1.2, n_ml)
             out["ml_ggd"]["loss_vs_oracle"] = loss_delta(1, 1.2, ora, n_ml)
             ora.close()
-    eng.close()
+            # the paper's headline shape factor (README.md:155,165); beta < 1 is the ill-conditioned one
+            ora = oracle_after(1, 0.9, n_ml)
+            out["ml_ggd_beta0.9"] = {"workload": "the same net and data, MLflag=1, beta=0.9 (the paper's best shape factor); parity only, not timed",
+                                     "loss_vs_oracle": loss_delta(1, 0.9, ora, n_ml)}
+            ora.close()
+    wd.enter("teardown", 120, "ncclCommDestroy")
+    if eng is not None:
+        eng.close()
     if world > 1:
+        last_coll["what"] = "gloo barrier (teardown)"
         dist.barrier()
         dist.destroy_process_group()
+    wd.enter("done", 0)
     if rank == 0:
         print(json.dumps(out), flush=True)
+    return 0
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if "MLGGD_DP_MODE" in os.environ and "MLGGD_DP_MODE_USER" not in os.environ:
+        os.environ["MLGGD_DP_MODE_USER"] = os.environ["MLGGD_DP_MODE"]  # --dp-mode auto keeps a mode the caller exported
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no torch import, no HIP call above this line: the children are the first processes to touch a GPU
+        sys.exit(launch_ranks(args, argv))
+    sys.exit(rank_main(args))
 
 
 if __name__ == "__main__":

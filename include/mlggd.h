@@ -156,6 +156,9 @@ int mlggd_debug_tensor(mlggd_handle h, const char *name, int layer, float *dst, 
  * different rows per rank); never run between two GPUs -- the mode thresholds are a cost model. */
 int mlggd_comm_unique_id(void *id /* MLGGD_UNIQUE_ID_BYTES */);
 int mlggd_comm_init(mlggd_handle h, const void *id, int world_size, int rank);
+/* what RCCL itself reports for the engine's communicator (ncclCommCount / ncclCommUserRank); 0 / -1 without one.
+ * bench.py prints it as `rccl_ranks` so a multi-GPU line proves the collectives ran over that many ranks. */
+int mlggd_comm_info(mlggd_handle h, int *nranks, int *rank);
 
 /* Per-step device time of the last mlggd_train_resident call, measured with HIP events
  * on the engine's stream: total ms over `steps` steps. */
@@ -191,6 +194,9 @@ int mlggd_dp_mode(mlggd_handle h, int *mode);
  * [r*bunchsize,(r+1)*bunchsize) of them.  mode: 0 = factor all-gather + replicated update, 1 = factor
  * all-gather + sharded update, 2 = gradient all-reduce. */
 int mlggd_debug_fake_world(mlggd_handle h, int world_size, int mode);
+/* Test hook: number of launch plans (tile-record tables) the persistent dW kernel has cached; constant after the
+ * first steps of a run (2 on one GPU, a few in the data-parallel modes). */
+int mlggd_debug_plan_count(mlggd_handle h, int *plans);
 
 /* Diagnostic (not part of the reference surface): in-kernel phase stamps of the NEXT launch of
  * (class "fwd"|"dx"|"dw", layer): 8 int64 slots per workgroup in 100 MHz ticks

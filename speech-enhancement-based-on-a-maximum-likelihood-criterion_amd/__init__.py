@@ -48,6 +48,7 @@ EXPORTS = [
     "mlggd_debug_stamp_select", "mlggd_debug_stamp_read",
     "mlggd_load_frames", "mlggd_train_frames", "mlggd_train_frames_async", "mlggd_cv_all_frames", "mlggd_forward_frames",
     "mlggd_alloc_pinned", "mlggd_alloc_pinned_on", "mlggd_free_pinned", "mlggd_set_cv_device_reduce",
+    "mlggd_comm_info", "mlggd_debug_plan_count",
 ]
 
 _lib = None
@@ -107,6 +108,8 @@ def load():
     L.mlggd_dw_launches_per_step.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     L.mlggd_dp_mode.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     L.mlggd_debug_fake_world.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.mlggd_comm_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.mlggd_debug_plan_count.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     L.mlggd_debug_stamp_select.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     L.mlggd_debug_stamp_read.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.c_int, C.POINTER(C.c_int)]
     _ip = C.POINTER(C.c_int32)
@@ -396,6 +399,17 @@ class BPGpu:
         """0 single device, 1 all-reduce of gradients, 2 all-gather of the gradient factors, 3 = 2 + sharded update"""
         n = C.c_int(0)
         _check(load().mlggd_dp_mode(self._h, C.byref(n)))
+        return n.value
+
+    def comm_info(self):
+        """(ranks, rank) of the engine's RCCL communicator as RCCL reports them; (0, -1) without one."""
+        n, r = C.c_int(0), C.c_int(-1)
+        _check(load().mlggd_comm_info(self._h, C.byref(n), C.byref(r)))
+        return n.value, r.value
+
+    def plan_count(self):
+        n = C.c_int(0)
+        _check(load().mlggd_debug_plan_count(self._h, C.byref(n)))
         return n.value
 
     def set_cv_device_reduce(self, on=True):

@@ -62,6 +62,8 @@ struct RcclApi {
     decltype(&ncclGetErrorString) GetErrorString_ = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;        // optional: mlggd_comm_info
+    decltype(&ncclCommUserRank) CommUserRank = nullptr;  // optional: mlggd_comm_info
     // fp32 sum / fp32 gather, the only forms the engine uses (the int arguments of the call sites are ignored: they
     // date from the hand-written prototypes and are kept so the call sites read like the NCCL API)
     int AllReduce(const void *s, void *r, size_t n, int, int, RcclComm c, hipStream_t st) const {
@@ -90,6 +92,8 @@ static int rccl_load() {
     g_rccl.GetErrorString_ = (decltype(&ncclGetErrorString))dlsym(lib, "ncclGetErrorString");
     g_rccl.GroupStart = (decltype(&ncclGroupStart))dlsym(lib, "ncclGroupStart");
     g_rccl.GroupEnd = (decltype(&ncclGroupEnd))dlsym(lib, "ncclGroupEnd");
+    g_rccl.CommCount = (decltype(&ncclCommCount))dlsym(lib, "ncclCommCount");
+    g_rccl.CommUserRank = (decltype(&ncclCommUserRank))dlsym(lib, "ncclCommUserRank");
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce_ || !g_rccl.AllGather_ || !g_rccl.CommDestroy ||
         !g_rccl.GroupStart || !g_rccl.GroupEnd)
         return fail(MLGGD_ERR_COMM, "librccl is missing required symbols");
@@ -309,7 +313,7 @@ static int log2_or_minus1(int d) {  // for divmod_by in the kernels
     return -1;
 }
 static FwdArgs fwd_args(mlggd_engine *e, int l, float *Yrow_out) {
-    FwdArgs a;
+    FwdArgs a{};
     a.W = e->W[l];
     a.Yt_in = e->Yt[l - 1];
     a.bias = e->bias[l];
@@ -330,7 +334,7 @@ static FwdArgs fwd_args(mlggd_engine *e, int l, float *Yrow_out) {
 }
 
 static DxArgs dx_args(mlggd_engine *e, int l) {
-    DxArgs a;
+    DxArgs a{};
     a.W = e->W[l];
     a.dEdXt = e->dEdXt[l];
     a.Yt_prev = e->Yt[l - 1];
@@ -348,6 +352,7 @@ static DxArgs dx_args(mlggd_engine *e, int l) {
 
 static DwpArgs dwp_args(mlggd_engine *e, int l, const float *in_rows, const float *Yrow_prev, float nf) {
     DwpArgs a;
+    memset(&a, 0, sizeof(a));  // every byte, tail padding included: dwp_table compares plans with memcmp
     const int Kp = e->lsp[l - 1], Np = e->lsp[l];
     a.Yrow = (l == 1) ? in_rows : Yrow_prev;
     a.dEdX = e->dEdX[l];
@@ -579,18 +584,32 @@ static DwpJobs dwp_jobs(mlggd_engine *e, int lhi, int llo, const float *in_rows,
 // run uses two plans (the layer-1 operand alternates between the two staged-row buffers), a data-parallel run
 // a few more.  Hyper-parameters are not part of the plan: they travel in DwpConst with every launch.
 static int dwp_table(mlggd_engine *e, const DwpJobs &J, bool fused, int grid, const DwpDesc **out) {
-    DwpJobs key = J;
-    for (int j = 0; j < DWP_MAXJOBS; j++) {
+    // The key is rebuilt field by field into zeroed storage, so padding bytes (DwpArgs has 4 at its tail) and the
+    // unused job slots never take part in the memcmp.  Hyper-parameters and the frame count are not part of a plan.
+    DwpJobs key;
+    memset(&key, 0, sizeof(key));
+    for (int j = 0; j < J.njobs && j < DWP_MAXJOBS; j++) {
+        const DwpArgs &s = J.job[j];
         DwpArgs &a = key.job[j];
-        if (j >= J.njobs) memset(&a, 0, sizeof(a));
-        a.nf = a.mom = a.lr = a.wc = 0.0f;
-        a.B = 0;
+        a.Yrow = s.Yrow; a.dEdX = s.dEdX; a.Wt = s.Wt; a.delta = s.delta; a.G = s.G;
+        a.bias = s.bias; a.dbias = s.dbias; a.gb = s.gb;
+        a.ldA = s.ldA; a.K = s.K; a.N = s.N; a.Kp = s.Kp; a.Np = s.Np; a.n_wg = s.n_wg; a.ntiles = s.ntiles;
+        a.k_first = s.k_first; a.wd_off = s.wd_off; a.do_bias = s.do_bias;
+        key.tile_end[j] = J.tile_end[j];
     }
+    key.njobs = J.njobs;
+    key.total = J.total;
     for (const auto &t : e->dwp_tables)
         if (t.fused == fused && t.grid == grid && memcmp(&t.key, &key, sizeof(key)) == 0) {
             *out = t.dev;
             return MLGGD_OK;
         }
+    // A run uses two plans on one GPU (the layer-1 operand alternates between the two staged-row buffers) and a
+    // handful more in the data-parallel modes.  A miss costs a hipMalloc and a blocking copy in the middle of a
+    // step, so a plan count that keeps growing is a bug (a key that never matches): fail loudly, do not leak.
+    if (e->dwp_tables.size() >= 64)
+        return fail(MLGGD_ERR_STATE, "dW tile table: %zu launch plans cached and still missing -- plan key unstable",
+                    e->dwp_tables.size());
     std::vector<DwpDesc> recs((size_t)J.total + 2 * (size_t)grid);
     size_t n = 0;
     for (int j = 0; j < J.njobs; j++) {
@@ -1561,8 +1580,18 @@ int mlggd_alloc_pinned(size_t bytes, void **out) {
 }
 int mlggd_alloc_pinned_on(int device, size_t bytes, void **out) {
     if (!out) return fail(MLGGD_ERR_ARG, "out is NULL");
-    HIPCHK(hipSetDevice(device));  // the calling thread may have no current device yet (a host IO thread)
-    HIPCHK(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev)  // the same message mlggd_create gives (BP_GPU.cu:17-21)
+        return fail(MLGGD_ERR_ARG, "GPU Num %d Not In Range %d-%d", device, 0, ndev - 1);
+    // the calling thread may have no current device yet (a host IO thread): pin through `device`'s context, then
+    // put the thread's current device back so the call has no side effect on it
+    int prev = -1;
+    const bool had_prev = hipGetDevice(&prev) == hipSuccess;
+    HIPCHK(hipSetDevice(device));
+    const hipError_t err = hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault);
+    if (had_prev && prev != device) hipSetDevice(prev);
+    if (err != hipSuccess) return fail(MLGGD_ERR_DEVICE, "hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(err));
     return MLGGD_OK;
 }
 int mlggd_free_pinned(void *p) {
@@ -1995,6 +2024,26 @@ int mlggd_debug_fake_world(mlggd_handle e, int world_size, int mode) {
     CHK(gather_alloc(e));
     if (mode == 1) CHK(shard_alloc(e));
     HIPCHK(hipStreamSynchronize(e->stream));
+    return MLGGD_OK;
+}
+// size and rank of the RCCL communicator as RCCL itself reports them (ncclCommCount / ncclCommUserRank);
+// 0 / -1 without a communicator
+int mlggd_comm_info(mlggd_handle e, int *nranks, int *rank) {
+    if (!e) return fail(MLGGD_ERR_ARG, "NULL handle");
+    int n = 0, r = -1;
+    if (e->comm) {
+        if (!g_rccl.CommCount || !g_rccl.CommUserRank) return fail(MLGGD_ERR_COMM, "librccl lacks ncclCommCount / ncclCommUserRank");
+        NCCLCHK(g_rccl.CommCount(e->comm, &n));
+        NCCLCHK(g_rccl.CommUserRank(e->comm, &r));
+    }
+    if (nranks) *nranks = n;
+    if (rank) *rank = r;
+    return MLGGD_OK;
+}
+// number of cached launch plans of the persistent dW kernel (tests: it must not grow with the step count)
+int mlggd_debug_plan_count(mlggd_handle e, int *plans) {
+    if (!e || !plans) return fail(MLGGD_ERR_ARG, "NULL argument");
+    *plans = (int)e->dwp_tables.size();
     return MLGGD_OK;
 }
 int mlggd_dp_mode(mlggd_handle e, int *mode) {

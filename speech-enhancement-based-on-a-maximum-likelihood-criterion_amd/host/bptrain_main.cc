@@ -75,6 +75,7 @@ void swap_buffers(Interface *io, bool frames) {  // BPtrain.cc:25-32
 // threadFetch, BPtrain.cc:15-54
 std::atomic<bool> g_stop_fetch{false};  // set when the trainer gives up before consuming every chunk
 int g_pinned_device = 0;                // device whose context owns the page-locked chunk buffers
+std::string g_pinned_error;             // engine's message when a page-locked allocation failed (fetch thread only)
 
 void fetch_loop(Interface *io, Slot *slot, std::string *error, bool frames) {
     try {
@@ -89,6 +90,8 @@ void fetch_loop(Interface *io, Slot *slot, std::string *error, bool frames) {
         }
     } catch (const std::exception &e) {
         *error = e.what();
+        // the reader only knows "no buffer"; the engine knows why (e.g. gpu_used= names no device)
+        if (!g_pinned_error.empty()) *error += ": " + g_pinned_error;
         io->cur_chunk_samples = -1;
         slot->set(true);
     }
@@ -159,7 +162,8 @@ int main(int argc, char *argv[]) {
                 [](size_t n) -> void * {
                     void *q = nullptr;
                     if (mlggd_alloc_pinned_on(g_pinned_device, n, &q) != MLGGD_OK) {
-                        fprintf(stderr, "page-locked chunk buffer of %zu bytes: %s\n", n, mlggd_last_error());
+                        g_pinned_error = mlggd_last_error();
+                        fprintf(stderr, "page-locked chunk buffer of %zu bytes: %s\n", n, g_pinned_error.c_str());
                         return nullptr;
                     }
                     return q;

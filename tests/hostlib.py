@@ -1,4 +1,4 @@
-"""ctypes access to the real C++ host code (host/libmlggd_host.so) + independent NumPy
+"""ctypes access to the real C++ host code (tests/host_api.cc -> tests/libmlggd_host.so, built by host/Makefile) + independent NumPy
 restatements of the reference's host algorithms for cross-checking (Interface.cc)."""
 import ctypes as C
 import os
@@ -15,8 +15,8 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        subprocess.check_call(["make", "-C", HOST, "-s", "libmlggd_host.so", "gen_rand_net"])
-        L = C.CDLL(os.path.join(HOST, "libmlggd_host.so"))
+        subprocess.check_call(["make", "-C", HOST, "-s", "../../tests/libmlggd_host.so", "gen_rand_net"])
+        L = C.CDLL(os.path.join(ROOT, "tests", "libmlggd_host.so"))
         L.mlggd_host_open.restype = C.c_void_p
         L.mlggd_host_open.argtypes = [C.c_int, C.POINTER(C.c_char_p)]
         L.mlggd_host_close.argtypes = [C.c_void_p]

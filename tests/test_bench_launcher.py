@@ -1,0 +1,83 @@
+"""bench.py's own multi-rank launch path, on the CPU (no GPU is touched: --dry-launch stops after the gloo rendezvous).
+
+The driver runs `python bench.py --gpus N --steps K --warmup W` for N > 1 as well as the torchrun form; both must
+reach the ranks' rendezvous.  (Round 2: the first form exited with status 1 before starting anything.)"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env(**kw):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(kw)
+    return env
+
+
+def _json_line(stdout):
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_self_launch_reaches_the_rendezvous(world):
+    r = subprocess.run([sys.executable, BENCH, "--gpus", str(world), "--steps", "20", "--warmup", "5", "--dry-launch"],
+                       capture_output=True, text=True, timeout=300, env=_env())
+    assert r.returncode == 0, r.stderr
+    d = _json_line(r.stdout)
+    assert d["dry_launch"] and d["world"] == world and d["backend"] == "gloo"
+    assert d["ranks"] == list(range(world)) and d["local_ranks"] == list(range(world))
+    assert d["distinct_pids"] == world and d["launched_by"] == "bench.py" and d["gpu_touched"] is False
+
+
+def test_torchrun_form_reaches_the_rendezvous():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), BENCH, "--gpus", "2", "--steps", "20",
+                        "--warmup", "5", "--dry-launch"], capture_output=True, text=True, timeout=300, env=_env())
+    assert r.returncode == 0, r.stderr
+    d = _json_line(r.stdout)
+    assert d["world"] == 2 and d["ranks"] == [0, 1] and d["launched_by"] == "external launcher"
+
+
+def test_single_rank_dry_launch_stays_in_process():
+    r = subprocess.run([sys.executable, BENCH, "--dry-launch"], capture_output=True, text=True, timeout=300, env=_env())
+    assert r.returncode == 0, r.stderr
+    d = _json_line(r.stdout)
+    assert d["world"] == 1 and d["launched_by"] == "direct"
+
+
+def test_without_a_gpu_the_failure_is_the_missing_gpu_not_the_launcher():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the real run is covered by the gpu tests")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1"], capture_output=True,
+                       text=True, timeout=300, env=_env())
+    assert r.returncode == 1
+    assert r.stderr.count("bench.py needs a GPU") == 2, r.stderr  # both ranks were started and said so
+    assert "torch.distributed.run" not in r.stderr
+
+
+def test_a_rank_that_dies_takes_the_launch_down_with_its_status():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-launch"], capture_output=True, text=True, timeout=300,
+                       env=_env(MLGGD_BENCH_TEST_FAIL_RANK="1", MLGGD_BENCH_GRACE_S="2"))
+    assert r.returncode == 7, (r.returncode, r.stderr)
+    assert "rank 1 exited with status 7" in r.stderr
+
+
+def test_watchdog_names_rank_and_phase():
+    # rank 1 never arrives; its watchdog (budget 60 s x 0.02) says where it sat and exits 3, the launcher stops rank 0
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-launch"], capture_output=True, text=True, timeout=300,
+                       env=_env(MLGGD_BENCH_TEST_HANG_RANK="1", MLGGD_BENCH_WATCHDOG_SCALE="0.02", MLGGD_BENCH_GRACE_S="2"))
+    assert r.returncode == 3, (r.returncode, r.stderr)
+    assert "bench watchdog: rank 1 of 2 stuck in phase 'test hang'" in r.stderr
