@@ -1,6 +1,7 @@
 // host_api.cc -- C entry points over trainer_io for the CPU test-suite (ctypes): lets
 // tests/ drive the real host code (CLI parse, pfile reader, chunk planner, chunk reader,
 // .wts writer) without a GPU and compare it with an independent NumPy restatement.
+#include <cstdio>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -96,6 +97,56 @@ int mlggd_host_read_chunk_frames(void *h, int index, int cv, float *feat, float 
         g_err = e.what();
         return -1;
     }
+}
+
+// One parsed command-line field of WorkPara as text (ints "%d", floats "%.9g": enough digits to round-trip a float),
+// by the key=value name Interface::Initial knows it under (Interface.cc:150-315); "numlayers" is the layer count the
+// parser DERIVED from layersizes= (the key numlayers= itself is not a key of the reference's parser).
+// Returns the length, -1 for an unknown key.
+int mlggd_host_para(void *h, const char *key, char *out, int cap) {
+    Interface *io = (Interface *)h;
+    const WorkPara *p = io->para;
+    const std::string k(key);
+    std::string v;
+    char buf[64];
+    auto I = [&](int x) { snprintf(buf, sizeof(buf), "%d", x); v = buf; };
+    auto F = [&](float x) { snprintf(buf, sizeof(buf), "%.9g", (double)x); v = buf; };
+    if (k == "fea_file") v = p->fea_FN;
+    else if (k == "norm_file") v = p->fea_normFN;
+    else if (k == "targ_file") v = p->targ_FN;
+    else if (k == "outwts_file") v = p->out_weightFN;
+    else if (k == "log_file") v = p->log_FN;
+    else if (k == "initwts_file") v = p->init_weightFN;
+    else if (k == "train_sent_range") v = p->train_sent_range;
+    else if (k == "cv_sent_range") v = p->cv_sent_range;
+    else if (k == "fea_dim") I(p->fea_dim);
+    else if (k == "fea_context") I(p->fea_context);
+    else if (k == "targ_offset") I(p->targ_offset);
+    else if (k == "dropoutflag") I(p->dropoutflag);
+    else if (k == "MLflag") I(p->MLflag);
+    else if (k == "traincache") I(p->traincache);
+    else if (k == "bunchsize") I(p->bunchsize);
+    else if (k == "gpu_used") I(p->gpu_used);
+    else if (k == "init_randem_seed") I(p->init_randem_seed);
+    else if (k == "momentum") F(p->momentum);
+    else if (k == "shapefactor") F(p->shapefactor);
+    else if (k == "weightcost") F(p->weightcost);
+    else if (k == "lrate") F(p->lrate);
+    else if (k == "visible_omit") F(p->visible_omit);
+    else if (k == "hid_omit") F(p->hid_omit);
+    else if (k == "init_randem_weight_min") F(p->init_randem_weight_min);
+    else if (k == "init_randem_weight_max") F(p->init_randem_weight_max);
+    else if (k == "init_randem_bias_min") F(p->init_randem_bias_min);
+    else if (k == "init_randem_bias_max") F(p->init_randem_bias_max);
+    else if (k == "numlayers") I(io->numlayers);
+    else if (k == "layersizes") {
+        for (int i = 0; i < io->numlayers; i++) {
+            snprintf(buf, sizeof(buf), i ? ",%d" : "%d", p->layersizes[i]);
+            v += buf;
+        }
+    } else return -1;
+    snprintf(out, cap, "%s", v.c_str());
+    return (int)v.size();
 }
 
 void mlggd_host_shuffle(void *h, int *vec, int len) { ((Interface *)h)->GetRandIndex(vec, len); }

@@ -28,6 +28,7 @@ def lib():
         L.mlggd_host_read_chunk_frames.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float),
                                                    C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.mlggd_host_shuffle.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int]
+        L.mlggd_host_para.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int]
         L.mlggd_host_weights.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.mlggd_host_write_pfile.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(C.c_float)]
         L.mlggd_host_rank_rows.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]
@@ -106,6 +107,13 @@ class HostIO:
         if n < 0:
             raise HostError(lib().mlggd_host_last_error().decode())
         return feat[:nfr.value], targ[:nfr.value], first[:n]
+
+    def para(self, key):
+        """one parsed WorkPara field as text (ints %d, floats %.9g, strings as stored)"""
+        buf = C.create_string_buffer(4096)
+        if lib().mlggd_host_para(self.h, key.encode(), buf, len(buf)) < 0:
+            raise KeyError(key)
+        return buf.value.decode()
 
     def shuffle(self, n):
         v = (C.c_int * n)(*range(n))
@@ -187,6 +195,13 @@ class Rand48:
         if n < 0:
             raise HostError(lib().mlggd_host_last_error().decode())
         return feat[:nfr.value], targ[:nfr.value], first[:n]
+
+    def para(self, key):
+        """one parsed WorkPara field as text (ints %d, floats %.9g, strings as stored)"""
+        buf = C.create_string_buffer(4096)
+        if lib().mlggd_host_para(self.h, key.encode(), buf, len(buf)) < 0:
+            raise KeyError(key)
+        return buf.value.decode()
 
     def shuffle(self, n):  # Interface::GetRandIndex, Interface.cc:975-986
         v = list(range(n))

@@ -1,9 +1,13 @@
 """CPU: the C++ host code (CLI, norm, .wts, pfile reader, chunk planner, chunk reader,
 lrand48 shuffles) against independent restatements, synthetic pfiles, and -- in the build
 container only -- the reference's own sample pfiles/norm file (SURVEY.md 4 / 8c KATs)."""
+import json
 import os
+import re
+import shutil
 import struct
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -288,3 +292,88 @@ def test_rendezvous_never_accepts_a_stale_id_file(tmp_path):
     # a rank whose peers never show up gives up with a message instead of hanging
     with pytest.raises(hostlib.HostError, match="timed out"):
         hostlib.rendezvous(path, 2, 1, None, timeout=0.2)
+
+
+FINETUNE = "/root/reference/Train_code_ML_GGD/finetune.pl"
+
+
+@pytest.mark.skipif(not (os.path.exists(FINETUNE) and shutil.which("perl")), reason="reference tree / perl not present")
+def test_reference_finetune_pl_argv_through_the_parser(tmp_path):
+    """the reference's epoch driver `finetune.pl` must run unmodified against the new binary
+    except `$exe`.  The script itself is run here by perl (in-container only; nothing of it is committed or shipped:
+    a temporary copy gets its `$exe` line pointed at a recorder), and every argv its three system() call sites emit
+    (finetune.pl:50-76 epoch 1, :89-115 epochs 2-10, :127-153 epochs 11-50) goes through Interface::Initial; each
+    key must land where the reference's parser puts it (Interface.cc:150-315): strings verbatim, ints by atoi,
+    floats by atof -> float; `numlayers=` is not a key of that parser (the count comes from layersizes=)."""
+    top = tmp_path / "ref"
+    tc = top / "Train_code_ML_GGD"
+    (tc / "pretraining_weights").mkdir(parents=True)
+    os.symlink("/root/reference/tools_pfile", top / "tools_pfile")  # $ROOT_DIR/tools_pfile = the reference's sample data
+    script = open(FINETUNE).read()
+    rec = tc / "recorder.py"
+    log = tc / "argv.jsonl"
+    rec.write_text("#!%s\nimport json, os, sys\n"
+                   "open(%r, 'a').write(json.dumps(sys.argv[1:]) + '\\n')\n"
+                   "kv = dict(a.split('=', 1) for a in sys.argv[1:])\n"
+                   "# the next epoch starts from this epoch's output: stand in for it with the initial weights\n"
+                   "os.symlink(os.path.realpath(kv['initwts_file']), kv['outwts_file'])\n" % (sys.executable, str(log)))
+    rec.chmod(0o755)
+    patched, n = re.subn(r'(my \$exe\s*=\s*)"[^"]*";', lambda m: m.group(1) + '"./recorder.py";', script)
+    assert n == 1  # the ONE line a user edits
+    (tc / "finetune.pl").write_text(patched)
+    # the init file finetune.pl:47 names is not shipped by the reference: gen_rand_net makes it (SURVEY 8f3)
+    ls = [1799, 2048, 2048, 2048, 257]
+    hostlib.lib()
+    subprocess.check_call([os.path.join(hostlib.HOST, "gen_rand_net"), "5", *map(str, ls), str(tc / "pretraining_weights"),
+                           str(tc / "pretraining_weights" / "Rand_1799_3hid2048_257_beta2.wts"), "1", "2", "5"],
+                          stdout=subprocess.DEVNULL)
+    r = subprocess.run(["perl", "finetune.pl"], cwd=tc, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    argvs = [json.loads(x) for x in open(log)]
+    assert len(argvs) == 50  # one process per epoch
+    assert all(len(a) == 25 and a[1] == "numlayers=5" for a in argvs)
+
+    seed, lrate = 27870775, 0.1
+    for epoch in (1, 2, 10, 11, 12, 50):
+        argv = argvs[epoch - 1]
+        kv = dict(a.split("=", 1) for a in argv)
+        cwd = os.getcwd()
+        os.chdir(tc)  # the script's paths are relative to its directory
+        try:
+            io = hostlib.HostIO.raw(argv)
+        finally:
+            os.chdir(cwd)
+        for key in ("fea_file", "norm_file", "targ_file", "outwts_file", "log_file", "initwts_file", "train_sent_range",
+                    "cv_sent_range"):
+            assert io.para(key) == kv[key], key
+        for key in ("fea_dim", "fea_context", "targ_offset", "dropoutflag", "MLflag", "traincache", "bunchsize", "gpu_used",
+                    "init_randem_seed"):
+            assert int(io.para(key)) == int(kv[key]), key
+        for key in ("momentum", "shapefactor", "weightcost", "lrate", "visible_omit", "hid_omit"):
+            assert np.float32(float(io.para(key))) == np.float32(float(kv[key])), key  # atof -> float
+        assert io.para("layersizes") == "1799,2048,2048,2048,257" and int(io.para("numlayers")) == 5
+        # keys the script never passes keep the reference's defaults (Interface.cc:140-143)
+        assert [float(io.para("init_randem_%s" % k)) for k in ("weight_min", "weight_max", "bias_min", "bias_max")] == \
+            [np.float32(-0.1), np.float32(0.1), np.float32(-0.1), np.float32(0.1)]
+        # the schedule finetune.pl implements (:27,31,80,86,118-123): seed += 345 per epoch, lr x0.9 from epoch 11 on
+        assert int(io.para("init_randem_seed")) == seed + 345 * (epoch - 1)
+        want_lr = lrate * 0.9 ** max(0, epoch - 10)
+        assert abs(float(io.para("lrate")) - want_lr) <= 1e-6 * want_lr
+        assert kv["outwts_file"] == "./MLGGD1/mlp.%d.wts" % epoch and kv["log_file"] == "./MLGGD1/mlp.%d.log" % epoch
+        assert kv["initwts_file"] == ("./pretraining_weights/Rand_1799_3hid2048_257_beta2.wts" if epoch == 1
+                                      else "./MLGGD1/mlp.%d.wts" % (epoch - 1))
+        # the sample pfiles the script points at were really opened: 10 sentences, 1885 frames (SURVEY.md 4)
+        sents, frames, _, nl = io.info()
+        assert (sents, frames, nl) == (10, 1885, 5)
+        io.close()
+
+    # numlayers= is ignored even when it contradicts layersizes= (the reference never parses it)
+    argv = [a if not a.startswith("numlayers=") else "numlayers=9" for a in argvs[0]]
+    cwd = os.getcwd()
+    os.chdir(tc)
+    try:
+        io = hostlib.HostIO.raw(argv)
+    finally:
+        os.chdir(cwd)
+    assert int(io.para("numlayers")) == 5
+    io.close()
