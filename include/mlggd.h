@@ -198,6 +198,12 @@ int mlggd_debug_fake_world(mlggd_handle h, int world_size, int mode);
  * first steps of a run (2 on one GPU, a few in the data-parallel modes). */
 int mlggd_debug_plan_count(mlggd_handle h, int *plans);
 
+/* Diagnostic: out[i] = fn(x[i], y) evaluated on the device with the libm calls the kernels themselves use -- fn "powf"
+ * (kernindex2 / kernfunc2 / kernSubClean2, DevFunc.cu:219-227,468-489,376-398), "expf", "sigmoid" = 1/(1+expf(-x))
+ * (kernSigmoid, DevFunc.cu:36-51), "div" = x / y.  Parity tests use it to state, in ulps, how far the device's libm
+ * sits from the oracle's: the one part of the loss chain that is not bit-exact IEEE arithmetic on both sides. */
+int mlggd_debug_math(mlggd_handle h, const char *fn, const float *x, float y, float *out, size_t n);
+
 /* Diagnostic (not part of the reference surface): in-kernel phase stamps of the NEXT launch of
  * (class "fwd"|"dx"|"dw", layer): 8 int64 slots per workgroup in 100 MHz ticks
  * (s_memrealtime); slot meaning per kernel is documented at stamp() call sites in

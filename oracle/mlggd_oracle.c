@@ -151,23 +151,41 @@ static void ensure_frames(ora_net *net, int frames) {
 
 /* SgemmNN, DevFunc.h:65-75 <- BP_GPU.cu:361,494 : X[B][N] = 1*(Y[B][K] . W[K][N]) + 1*X.
  * Order: dot product over k = 0..K-1 ascending from 0.0f, then + old X (the bias). */
+/* Summation-order twin (ambiguity ii made measurable).  split = 1 (default): the orders documented at each gemm_*
+ * below -- the oracle every parity test compares against.  split = S > 1: the reduction index of the forward and dX
+ * GEMMs is cut into S contiguous ranges, each summed ascending from 0.0f, the S partial sums added in range order --
+ * the shape of order a split-K GEMM has (the HIP kernels split K over 4 waves; cuBLAS picks its own, unspecified
+ * split).  Both are equally valid readings of `cublasSgemm`; the distance between the two after N steps is what a
+ * mere change of GEMM summation order does to a trajectory, which is what tests bound the HIP path against. */
+static int g_gemm_split = 1;
+void ora_set_gemm_split(int s) { g_gemm_split = s < 1 ? 1 : s; }
+
 static void gemm_fwd(int B, int K, int N, const float *Y, const float *W, float *X) {
     enum { JB = 128 };
     const int nblk = (N + JB - 1) / JB;
+    const int S = g_gemm_split;
 #pragma omp parallel
     {
         float *acc = (float *)malloc((size_t)B * JB * sizeof(float));
+        float *part = S > 1 ? (float *)malloc((size_t)B * JB * sizeof(float)) : NULL;
 #pragma omp for schedule(dynamic, 1)
         for (int jb = 0; jb < nblk; jb++) {
             const int j0 = jb * JB, jw = (N - j0 < JB) ? N - j0 : JB;
             memset(acc, 0, (size_t)B * JB * sizeof(float));
-            for (int k = 0; k < K; k++) {
-                const float *w = W + (size_t)k * N + j0;
-                for (int b = 0; b < B; b++) {
-                    const float yv = Y[(size_t)b * K + k];
-                    float *a = acc + (size_t)b * JB;
-                    for (int j = 0; j < jw; j++) a[j] += yv * w[j];
+            for (int sp = 0; sp < S; sp++) {
+                float *dst = S > 1 ? part : acc;
+                if (S > 1) memset(part, 0, (size_t)B * JB * sizeof(float));
+                const int k_lo = (int)((long)K * sp / S), k_hi = (int)((long)K * (sp + 1) / S);
+                for (int k = k_lo; k < k_hi; k++) {
+                    const float *w = W + (size_t)k * N + j0;
+                    for (int b = 0; b < B; b++) {
+                        const float yv = Y[(size_t)b * K + k];
+                        float *a = dst + (size_t)b * JB;
+                        for (int j = 0; j < jw; j++) a[j] += yv * w[j];
+                    }
                 }
+                if (S > 1)
+                    for (size_t i = 0; i < (size_t)B * JB; i++) acc[i] = sp == 0 ? part[i] : acc[i] + part[i];
             }
             for (int b = 0; b < B; b++)
                 for (int j = 0; j < jw; j++) {
@@ -176,6 +194,7 @@ static void gemm_fwd(int B, int K, int N, const float *Y, const float *W, float 
                 }
         }
         free(acc);
+        free(part);
     }
 }
 
@@ -183,6 +202,25 @@ static void gemm_fwd(int B, int K, int N, const float *Y, const float *W, float 
  * Order: eight interleaved partial sums q = j mod 8, each over ascending j, combined as
  * ((s0+s1)+(s2+s3))+((s4+s5)+(s6+s7)). */
 static void gemm_dx(int B, int K, int N, const float *dEdX, const float *W, float *dEdY) {
+    const int S = g_gemm_split;
+    if (S > 1) { /* order twin: S contiguous ranges of j, each ascending from 0.0f, added in range order */
+#pragma omp parallel for schedule(static)
+        for (int k = 0; k < K; k++) {
+            const float *w = W + (size_t)k * N;
+            for (int b = 0; b < B; b++) {
+                const float *d = dEdX + (size_t)b * N;
+                float tot = 0.0f;
+                for (int sp = 0; sp < S; sp++) {
+                    const int j_lo = (int)((long)N * sp / S), j_hi = (int)((long)N * (sp + 1) / S);
+                    float part = 0.0f;
+                    for (int j = j_lo; j < j_hi; j++) part += d[j] * w[j];
+                    tot = sp == 0 ? part : tot + part;
+                }
+                dEdY[(size_t)b * K + k] = tot;
+            }
+        }
+        return;
+    }
 #pragma omp parallel for schedule(static)
     for (int k = 0; k < K; k++) {
         const float *w = W + (size_t)k * N;

@@ -53,6 +53,7 @@ def lib(variant="strict"):
         L.ora_tensor.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_long)]
         L.ora_num_threads.restype = C.c_int
         L.ora_set_num_threads.argtypes = [C.c_int]
+        L.ora_set_gemm_split.argtypes = [C.c_int]
         if "OMP_NUM_THREADS" not in os.environ:
             # a container often sees all host CPUs but may only use a share of them: more threads than
             # that share makes every OpenMP region slower, not faster
@@ -212,6 +213,13 @@ class OracleNet:
             a = a.reshape(-1, self.layersizes[layer])
             return a if rows is None else a[:rows]
         return a
+
+
+def set_gemm_split(s, variant="strict"):
+    """GEMM summation-order twin of the oracle (process-wide for that library): 1 = the documented orders;
+    S > 1 = forward / dX reductions as S contiguous partial sums (what a split-K GEMM does).  Tests use the distance
+    between the two to say what a mere change of summation order -- which cuBLAS leaves open -- does to a run."""
+    lib(variant).ora_set_gemm_split(int(s))
 
 
 def gamma(x):

@@ -48,7 +48,7 @@ EXPORTS = [
     "mlggd_debug_stamp_select", "mlggd_debug_stamp_read",
     "mlggd_load_frames", "mlggd_train_frames", "mlggd_train_frames_async", "mlggd_cv_all_frames", "mlggd_forward_frames",
     "mlggd_alloc_pinned", "mlggd_alloc_pinned_on", "mlggd_free_pinned", "mlggd_set_cv_device_reduce",
-    "mlggd_comm_info", "mlggd_debug_plan_count",
+    "mlggd_comm_info", "mlggd_debug_plan_count", "mlggd_debug_math",
 ]
 
 _lib = None
@@ -110,6 +110,7 @@ def load():
     L.mlggd_debug_fake_world.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.mlggd_comm_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.mlggd_debug_plan_count.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    L.mlggd_debug_math.argtypes = [C.c_void_p, C.c_char_p, _fp, C.c_float, _fp, C.c_size_t]
     L.mlggd_debug_stamp_select.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     L.mlggd_debug_stamp_read.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.c_int, C.POINTER(C.c_int)]
     _ip = C.POINTER(C.c_int32)
@@ -406,6 +407,13 @@ class BPGpu:
         n, r = C.c_int(0), C.c_int(-1)
         _check(load().mlggd_comm_info(self._h, C.byref(n), C.byref(r)))
         return n.value, r.value
+
+    def debug_math(self, fn, x, y=0.0):
+        """fn(x, y) elementwise on the device with the kernels' own libm ("powf" "expf" "sigmoid" "div")."""
+        x = _f32(x).ravel()
+        out = np.empty_like(x)
+        _check(load().mlggd_debug_math(self._h, fn.encode(), _p(x), float(y), _p(out), x.size))
+        return out
 
     def plan_count(self):
         n = C.c_int(0)

@@ -2052,6 +2052,34 @@ int mlggd_dp_mode(mlggd_handle e, int *mode) {
     return MLGGD_OK;
 }
 
+// Diagnostic: out[i] = fn(x[i], y) evaluated ON THE DEVICE with the same libm calls the kernels use
+// ("powf" "expf" "sigmoid" "div"); tests measure their distance to the oracle's host libm in ulps.
+int mlggd_debug_math(mlggd_handle e, const char *fn, const float *x, float y, float *out, size_t n) {
+    if (!e || !fn || (n > 0 && (!x || !out))) return fail(MLGGD_ERR_ARG, "NULL argument");
+    const int f = !strcmp(fn, "powf") ? 0 : !strcmp(fn, "expf") ? 1 : !strcmp(fn, "sigmoid") ? 2 : !strcmp(fn, "div") ? 3 : -1;
+    if (f < 0) return fail(MLGGD_ERR_ARG, "unknown function '%s'", fn);
+    if (n == 0) return MLGGD_OK;
+    HIPCHK(hipSetDevice(e->device));
+    float *dx = nullptr, *dout = nullptr;
+    HIPCHK(hipMalloc((void **)&dx, n * sizeof(float)));
+    if (hipMalloc((void **)&dout, n * sizeof(float)) != hipSuccess) {
+        hipFree(dx);
+        return fail(MLGGD_ERR_DEVICE, "hipMalloc of %zu bytes failed", n * sizeof(float));
+    }
+    int rc = MLGGD_OK;
+    if (hipMemcpyAsync(dx, x, n * sizeof(float), hipMemcpyHostToDevice, e->stream) != hipSuccess) rc = MLGGD_ERR_DEVICE;
+    if (rc == MLGGD_OK) {
+        hipLaunchKernelGGL(k_debug_math, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, f, dx, y, dout, n);
+        rc = launch_check("k_debug_math");
+    }
+    if (rc == MLGGD_OK && (hipMemcpyAsync(out, dout, n * sizeof(float), hipMemcpyDeviceToHost, e->stream) != hipSuccess ||
+                           hipStreamSynchronize(e->stream) != hipSuccess))
+        rc = fail(MLGGD_ERR_DEVICE, "mlggd_debug_math: copy back failed");
+    hipFree(dx);
+    hipFree(dout);
+    return rc;
+}
+
 // ---- per-kernel-class timing inside the timed region (bench.py roofline object)
 int mlggd_profile_select(mlggd_handle e, const char *kernel_class, int layer, int max_launches) {
     if (!e) return fail(MLGGD_ERR_ARG, "NULL handle");

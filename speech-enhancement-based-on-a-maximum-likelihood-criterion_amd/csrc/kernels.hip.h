@@ -1595,6 +1595,18 @@ __global__ __launch_bounds__(256) void k_apply_update(float *__restrict__ Wt, fl
     }
 }
 
+// Diagnostic (mlggd_debug_math): the device's own libm calls of the loss / activation epilogues applied to an
+// array, so a test can measure in ulps how far ocml's powf / expf sit from the correctly rounded result and from
+// the oracle's glibc -- the only arithmetic of the loss chain that is not IEEE-exact on both sides.
+//   fn 0: powf(x, y)   1: expf(x)   2: 1/(1+expf(-x)) (kernSigmoid, DevFunc.cu:48)   3: x / y
+__global__ __launch_bounds__(256) void k_debug_math(int fn, const float *__restrict__ x, float y, float *__restrict__ out,
+                                                    size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = x[i];
+    out[i] = fn == 0 ? powf(v, y) : fn == 1 ? expf(v) : fn == 2 ? 1.0f / (1.0f + expf(-v)) : v / y;
+}
+
 // does nothing: the kernel mlggd_profile_overhead brackets to calibrate what a HIP-event bracket costs by itself
 __global__ __launch_bounds__(256) void k_nop() {}
 

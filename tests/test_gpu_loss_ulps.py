@@ -1,0 +1,119 @@
+"""Where can the HIP loss chain differ from the oracle's AT ALL, given the same output-layer activations?
+
+VERDICT r02 asked for the origin of the beta = 0.9 distance (epoch-horizon CV numbers 1e-4 from the oracle where
+the oracle's own FMA twin sits 4e-5 away).  The loss chain (TC/BP_GPU.cu:413-423: kernerror, kernabsolutevalus,
+kernindex2, kernSumcol, kernDivide, kernVecMulNum, kernindex2, kernfunc2, kernVecMulNum; TC/DevFunc.cu:219-227,
+468-489) is IEEE-exact arithmetic in a fixed order on both sides EXCEPT its powf calls: the device's ocml powf and the
+oracle's glibc powf are different implementations of a function that neither rounds correctly.  So:
+
+  1. the device's powf / expf against the correctly rounded result and against glibc, in ulps;
+  2. the whole chain on an output layer whose activations are EXACTLY representable (small-integer inputs and
+     weights: every product and partial sum is exact in fp32, so `out` is bit-identical on both sides whatever the
+     GEMM summation order): dEdX_L and alpha in ulps, for the one-launch kernel (k_loss_ml) and for the
+     data-parallel pair (k_loss_err + k_loss_grad).
+
+Measured (MI355X, ROCm 7.2, r03): see the bounds below and DESIGN.md section 2.  Parity of the powf calls themselves
+is UNPINNED against the reference (CUDA's powf is a third implementation; no reference output exists)."""
+import ctypes
+import ctypes.util
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HP = (0.1, 0.9, 1e-5)
+
+
+def ulp_dist(a, b):
+    """distance in units in the last place between two float32 arrays (same sign assumed or zero)"""
+    a = np.ascontiguousarray(a, np.float32).view(np.int32).astype(np.int64)
+    b = np.ascontiguousarray(b, np.float32).view(np.int32).astype(np.int64)
+    a = np.where(a < 0, -(a & 0x7FFFFFFF), a)
+    b = np.where(b < 0, -(b & 0x7FFFFFFF), b)
+    return np.abs(a - b)
+
+
+def glibc_powf(x, y):
+    m = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6")
+    m.powf.restype = ctypes.c_float
+    m.powf.argtypes = [ctypes.c_float, ctypes.c_float]
+    return np.array([m.powf(float(v), float(y)) for v in x], np.float32)
+
+
+def tiny_engine(pkg, synth):
+    ls = [32, 32]
+    ws, bs = synth.make_weights(ls, seed=1)
+    return pkg.BPGpu(1, 0, ls, 32, *HP, ws, bs, 2.0, 0)
+
+
+def test_device_powf_and_expf_in_ulps(pkg, synth):
+    eng = tiny_engine(pkg, synth)
+    rng = np.random.default_rng(0)
+    # |e| of a normalised LPS regression: mostly 1e-3 .. 10, tails down to 1e-7
+    x = np.concatenate([np.exp(rng.uniform(np.log(1e-7), np.log(30.0), 60000)), np.abs(rng.normal(0, 1, 60000))]).astype(np.float32)
+    report = []
+    for y in (0.9, 1.2, 0.9 - 1.0, 1.2 - 1.0, 1.0 / 0.9, 1.0 / 1.2, 2.0):
+        y32 = np.float32(y)
+        dev = eng.debug_math("powf", x, y32)
+        exact = np.power(x.astype(np.float64), np.float64(y32)).astype(np.float32)
+        host = glibc_powf(x[:20000], y32)
+        d_dev, d_host, d_dh = ulp_dist(dev, exact), ulp_dist(host, exact[:20000]), ulp_dist(dev[:20000], host)
+        report.append((y, int(d_dev.max()), float((d_dev > 0).mean()), int(d_host.max()), float((d_host > 0).mean()),
+                       int(d_dh.max()), float((d_dh > 0).mean())))
+        assert d_dev.max() <= 2, (y, d_dev.max())        # ocml powf: within 2 ulp of the correctly rounded value
+        assert d_host.max() <= 1, (y, d_host.max())      # glibc powf: within 1 ulp
+    for r in report:
+        print("powf(x, %+.4f): device vs exact max %d ulp (%.1f %% differ) | glibc vs exact max %d ulp (%.1f %%) | "
+              "device vs glibc max %d ulp (%.1f %% differ)" % (r[0], r[1], 100 * r[2], r[3], 100 * r[4], r[5], 100 * r[6]))
+    # the sigmoid of the hidden layers (kernSigmoid, DevFunc.cu:48) -- not part of the loss chain, same question
+    v = rng.normal(0, 4, 100000).astype(np.float32)
+    dev = eng.debug_math("sigmoid", v)
+    e64 = np.exp(-v.astype(np.float64)).astype(np.float32)  # expf correctly rounded, then the two IEEE operations
+    exact = (np.float32(1) / (np.float32(1) + e64)).astype(np.float32)
+    d = ulp_dist(dev, exact)
+    print("sigmoid: device vs (correctly rounded expf, IEEE add / divide) max %d ulp (%.1f %% differ)" % (d.max(), 100 * (d > 0).mean()))
+    assert d.max() <= 2
+    # x / y is IEEE-exact on the device (hipcc's default correctly rounded fp32 division)
+    q = eng.debug_math("div", x, 3.7)
+    assert np.array_equal(q, (x / np.float32(3.7)).astype(np.float32))
+    eng.close()
+
+
+@pytest.mark.parametrize("beta", [0.9, 1.2, 2.0])
+@pytest.mark.parametrize("fused", [True, False])
+def test_loss_chain_on_an_exactly_representable_output_layer(pkg, pyoracle, beta, fused, monkeypatch):
+    """fused: k_loss_ml (single device, one launch); not fused: k_loss_err + k_loss_grad (the data-parallel pair)."""
+    monkeypatch.setenv("MLGGD_LOSS_FUSE", "1" if fused else "0")
+    K, D, B = 96, 257, 128
+    ls = [K, D]
+    rng = np.random.default_rng(7)
+    W = (rng.integers(-4, 5, (K, D)) * 0.125).astype(np.float32)   # multiples of 1/8, |w| <= 1/2
+    b = (rng.integers(-8, 9, D) * 0.25).astype(np.float32)
+    x = rng.integers(-3, 4, (B, K)).astype(np.float32)             # small integers
+    targ = rng.normal(0, 1.5, (B, D)).astype(np.float32)
+    targ[3, 5] = np.float32((x[3] @ W[:, 5]) + b[5])               # one exact hit: e == 0 -> g = 0 (kernfunc2's middle branch)
+    eng = pkg.BPGpu(1, 0, ls, B, *HP, [W], [b], beta, 1)
+    ora = pyoracle.OracleNet(ls, B, *HP, beta, 1, [W], [b])
+    assert eng.train(x, targ) == 1 and ora.train(x, targ) == 1
+    out_e, out_o = eng.debug_tensor("out"), ora.tensor("out", rows=B)
+    assert np.array_equal(out_e, out_o)                            # exact activations: bit-identical whatever the order
+    g_e, g_o = eng.debug_tensor("dedx", 1), ora.tensor("dedx", 1, rows=B)
+    gt_e = eng.debug_tensor("dedxt", 1)
+    assert np.array_equal(g_e, gt_e)                               # both layouts of the gradient hold the same bits
+    a_e, a_o = eng.scalefactor(), ora.tensor("scalefactor")
+    dg, da = ulp_dist(g_e, g_o), ulp_dist(a_e, a_o)
+    assert g_e[3, 5] == 0.0 and g_o[3, 5] == 0.0
+    assert np.array_equal(np.sign(g_e), np.sign(g_o))
+    print("beta %.1f %s: dEdX_L max %d ulp (%.1f %% of elements differ, mean %.2f ulp) | alpha max %d ulp (%.1f %% differ)"
+          % (beta, "k_loss_ml" if fused else "k_loss_err+k_loss_grad", dg.max(), 100 * (dg > 0).mean(), dg.mean(), da.max(),
+             100 * (da > 0).mean()))
+    if beta == 2.0:
+        # |e|^2 and |e|^1 .. powf(x, 2) and powf(x, 1) are exact in both libraries; alpha = powf(v, 0.5), alpha^2
+        assert da.max() <= 1 and dg.max() <= 4
+    else:
+        # every element's gradient is sgn(e) |e|^(beta-1) beta / alpha^beta / n: three powf results (each within
+        # 2 ulp of exact on the device, 1 ulp in glibc) and, through alpha, the sum of 128 more
+        assert da.max() <= 4 and dg.max() <= 12
+    eng.close()
+    ora.close()
