@@ -524,13 +524,32 @@ def rank_main(args):
             chk.close()
             return {k: (v if k == "steps" else float("%.2e" % v)) for k, v in d.items()}
 
-        def oracle_after(ml_, beta_, n_):
-            o = pyoracle.OracleNet(ls, B, 0.1, 0.9, 1e-5, beta_, ml_, ws, bs)
-            o.train_bunch(inp[:B], targ[:B])
-            o.train_bunch(inp[:B], targ[:B])
-            for i in range(n_):
-                o.train_bunch(inp[(i % nb) * B:(i % nb + 1) * B], targ[(i % nb) * B:(i % nb + 1) * B])
+        def oracle_after(ml_, beta_, n_, split=1):
+            pyoracle.set_gemm_split(split)
+            try:
+                o = pyoracle.OracleNet(ls, B, 0.1, 0.9, 1e-5, beta_, ml_, ws, bs)
+                o.train_bunch(inp[:B], targ[:B])
+                o.train_bunch(inp[:B], targ[:B])
+                for i in range(n_):
+                    o.train_bunch(inp[(i % nb) * B:(i % nb + 1) * B], targ[(i % nb) * B:(i % nb + 1) * B])
+            finally:
+                pyoracle.set_gemm_split(1)
             return o
+
+        def twin_delta(ml_, beta_, ora_, n_):
+            """The yardstick for loss_vs_oracle: the SAME oracle with another, equally valid GEMM summation order
+            (cuBLAS leaves the order open; oracle/mlggd_oracle.c "Summation-order twin") after the same steps."""
+            tw = oracle_after(ml_, beta_, n_, split=4)
+            cin, ctarg = synth.make_frames(1000, 257, 11, seed=77)
+            a = (tw.cv_sqerr(cin, ctarg), tw.cv_abserr(cin, ctarg), tw.cv_loglik(cin, ctarg), tw.tensor("scalefactor"))
+            b = (ora_.cv_sqerr(cin, ctarg), ora_.cv_abserr(cin, ctarg), ora_.cv_loglik(cin, ctarg), ora_.tensor("scalefactor"))
+            tw.close()
+            d = {"cv_sqerr_rel": abs(a[0] - b[0]) / abs(b[0]), "cv_abserr_rel": abs(a[1] - b[1]) / abs(b[1]),
+                 "cv_loglik_rel": abs(a[2] - b[2]) / abs(b[2]),
+                 "alpha_relmax": float(np.abs(a[3] - b[3]).max() / np.abs(b[3]).max())}
+            d = {k: float("%.2e" % v) for k, v in d.items()}
+            d["what"] = "oracle with forward/dX reductions as 4 contiguous partial sums vs the oracle itself: what a change of GEMM summation order alone does over these steps"
+            return d
 
         out["loss_vs_oracle"] = loss_delta(ml, beta, ora, n)
         ora.close()
@@ -538,11 +557,13 @@ def rank_main(args):
             n_ml = min(n, 150)
             ora = oracle_after(1, 1.2, n_ml)
             out["ml_ggd"]["loss_vs_oracle"] = loss_delta(1, 1.2, ora, n_ml)
+            out["ml_ggd"]["oracle_order_twin_vs_oracle"] = twin_delta(1, 1.2, ora, n_ml)
             ora.close()
             # the paper's headline shape factor (README.md:155,165); beta < 1 is the ill-conditioned one
             ora = oracle_after(1, 0.9, n_ml)
             out["ml_ggd_beta0.9"] = {"workload": "the same net and data, MLflag=1, beta=0.9 (the paper's best shape factor); parity only, not timed",
-                                     "loss_vs_oracle": loss_delta(1, 0.9, ora, n_ml)}
+                                     "loss_vs_oracle": loss_delta(1, 0.9, ora, n_ml),
+                                     "oracle_order_twin_vs_oracle": twin_delta(1, 0.9, ora, n_ml)}
             ora.close()
     wd.enter("teardown", 120, "ncclCommDestroy")
     if eng is not None:

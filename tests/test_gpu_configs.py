@@ -12,7 +12,7 @@ max|W| after a few steps, CV metrics 1e-4 relative (the north_star figure), alph
 After 800 steps two fp32 trajectories with different summation orders have drifted apart by more than a few
 steps' rounding; the epoch-horizon test states its own (measured) bounds for weights and alpha and keeps
 1e-4 for the three CV numbers the reference logs (BPtrain.cc:131-138) wherever the loss is well-conditioned
-(beta >= 1); for beta = 0.9 it documents the oracle's own build-to-build distance and bounds against that."""
+(beta >= 1); for beta = 0.9 the bound is derived inside the test from the oracle's own summation-order twins."""
 import os
 import re
 import subprocess
@@ -102,6 +102,57 @@ def test_config4_eight_ranks_at_the_real_shape(pkg, pyoracle, synth, mode):
     ora.close()
 
 
+def test_config5_eight_ranks_take_the_allreduce_exchange(pkg, pyoracle, synth):
+    """BASELINE config 5 in its 8-GPU form: 2827-4096^6-257, 512 frames per rank, ML-GGD beta 1.2, eight ranks
+    emulated on one GPU against the oracle with bunchsize 4096 on the same rows.  At 8 x 512 frames the
+    factor exchange is NOT usable (64 units of 64 gathered frames per tile; k_dwp is built for <= 16), so config 5 on
+    8 GPUs takes the all-reduce of the weight gradients -- BASELINE.json's own exchange: k_dwp<8,false> writes G_l
+    (386 MB over the 7 layers), the gradients are summed over the ranks, k_apply_update / k_bias_apply with
+    n = 4096.  The test asserts the mode so that the fallback is visible, not silent."""
+    ls, B, world, steps = synth.baseline_layersizes(hidden=4096, nhid=6), 512, 8, 2
+    ws, bs = synth.make_weights(ls, seed=61)
+    rng = np.random.default_rng(62)
+    bs = [rng.uniform(-0.1, 0.1, b.shape).astype(np.float32) for b in bs]
+    inp, targ = synth.make_frames(steps * world * B, 257, 11, seed=63)
+    eng = pkg.BPGpu(1, 0, ls, B, *HP, ws, bs, 1.2, 1)
+    with pytest.raises(pkg.MlggdError, match="fake world"):
+        eng.fake_world(world)                       # factor all-gather: refused at this shape
+    eng.fake_world(world, allreduce=True)
+    assert eng.dp_mode() == 1                       # 1 = all-reduce of the weight gradients
+    ora = pyoracle.OracleNet(ls, world * B, *HP, 1.2, 1, ws, bs)
+    assert eng.train(inp, targ) == steps and ora.train(inp, targ) == steps
+    we, be = eng.returnWeights()
+    wo, bo = ora.get_weights()
+    for l in range(len(we)):
+        assert relmax(we[l], wo[l]) < 2e-5, l
+        assert relmax(be[l], bo[l]) < 2e-5, l
+        assert relmax(eng.debug_tensor("delta_w", l + 1), ora.tensor("delta_w", l + 1)) < 5e-4, l
+        assert relmax(eng.debug_tensor("delta_b", l + 1), ora.tensor("delta_b", l + 1)) < 5e-4, l
+    assert relmax(eng.scalefactor(), ora.tensor("scalefactor")) < 1e-5
+    cin, ctarg = synth.make_frames(700, 257, 11, seed=64)
+    sq, ab, ll = eng.cv_all(cin, ctarg)
+    assert abs(sq - ora.cv_sqerr(cin, ctarg)) <= 1e-4 * abs(sq)
+    assert abs(ll - ora.cv_loglik(cin, ctarg)) <= 1e-4 * abs(ll)
+    eng.close()
+    ora.close()
+
+
+def test_launch_plan_cache_does_not_grow(pkg, synth):
+    """the tile-record tables of the persistent dW kernel are cached per launch plan; a key that never
+    matched would re-allocate and upload a table in the middle of every step.  One GPU: exactly two plans (the
+    layer-1 operand alternates between the two staged-row buffers), however many steps run."""
+    ls, B = synth.baseline_layersizes(hidden=256, nhid=2), 128
+    ws, bs = synth.make_weights(ls, seed=3)
+    inp, targ = synth.make_frames(12 * B, 257, 11, seed=4)
+    eng = pkg.BPGpu(1, 0, ls, B, *HP, ws, bs, 2.0, 0)
+    eng.train(inp, targ)
+    first = eng.plan_count()
+    for _ in range(3):
+        eng.train(inp, targ)
+    assert eng.plan_count() == first and 1 <= first <= 2
+    eng.close()
+
+
 def test_config1_executable_on_a_tiny_pfile_at_the_real_shape(pkg, pyoracle, tmp_path):
     """BASELINE config 1: BPtrain_Sigmoid with fea_dim=257 fea_context=11 layersizes=2827,2048,2048,2048,257
     MLflag=0 shapefactor=2 on a tiny synthetic pfile (10 sentences of ~190 frames): the weights file
@@ -172,50 +223,71 @@ def test_epoch_horizon_one_full_chunk_of_800_steps(pkg, pyoracle, synth, ml, bet
     the reference logs after an epoch (TC/BPtrain.cc:112-139: CV squared error, |error|/D, GGD log-likelihood)
     on a held-out chunk, and alpha, the per-dimension GGD scale the last step leaves behind (BP_GPU.cu:417-420).
 
-    beta >= 1 (MMSE, ML beta 1.2): CV numbers within 1e-4 relative (measured r02: 1e-6 .. 4e-6), alpha within
-    5e-4 of its maximum (8.6e-5), weights within 2e-3 of max|W| (1.5e-4 .. 8.4e-4: 800 steps of two fp32
-    trajectories with different summation orders).
+    beta >= 1 (MMSE, ML beta 1.2): CV numbers within 1e-4 relative -- the north_star figure -- (measured r02:
+    1e-6 .. 4e-6), alpha within 5e-4 of its maximum (8.6e-5), weights within 2e-3 of max|W| (1.5e-4 .. 8.4e-4:
+    800 steps of two fp32 trajectories with different summation orders).
 
-    beta = 0.9 is ill-conditioned BY THE LOSS, not by the implementation: the gradient sgn(e)|e|^(beta-1) jumps
-    between +-infinity-ish values where an error crosses zero, so any rounding difference is amplified along the
-    trajectory.  Measured on the oracle alone (tools/drift_oracle_variants.py, profiles/r02_oracle_variant_drift.txt):
-    the SAME C source built with and without FMA contraction -- two equally valid readings of the reference,
-    oracle/mlggd_oracle.c (viii) -- differs after these 800 steps by 4.3e-5 / 2.4e-5 / 2.4e-5 in the three CV
-    numbers, 5.7e-3 in alpha and 3.7e-2 of max|W| in the weights.  The HIP path sits 1.0e-4 / 4.2e-5 from the
-    strict oracle (r02).  The bound here is therefore 3e-4 on the CV numbers (a few times the oracle's own
-    build-to-build distance) and only sanity bounds on alpha and the weights."""
+    beta = 0.9 -- PARITY UNPINNED, and not reachable at 1e-4 by ANY implementation that is not bit-identical to the
+    reference build: the loss itself is ill-conditioned (the gradient sgn(e)|e|^(beta-1) jumps where an error
+    crosses zero and grows as |e| -> 0), so a trajectory amplifies rounding-level differences.  The bound is
+    therefore DERIVED IN THE TEST from the oracle alone: the same oracle is run with a different but
+    equally valid GEMM summation order (cuBLAS leaves it open, SURVEY 8a-ii: `ora_set_gemm_split`, reductions as 4
+    resp. 7 contiguous partial sums -- what any split-K GEMM does), and the HIP path must sit within K_TWIN = 4 times
+    the larger of the two twin-to-oracle distances, for the CV numbers, alpha (relative rms) and the weights
+    (relative rms) alike.  The loss chain itself agrees with the oracle to a few ulp when fed identical
+    activations (tests/test_gpu_loss_ulps.py): the distance measured here is the trajectory's, not a kernel's."""
     ls, B, n = synth.baseline_layersizes(), 128, 102400
     ws, bs = synth.make_weights(ls)
     inp, targ = synth.make_frames(n, 257, 11)
-    eng = pkg.BPGpu(synth.DEFAULT_SEED, 0, ls, B, *HP, ws, bs, beta, ml)
-    ora = pyoracle.OracleNet(ls, B, *HP, beta, ml, ws, bs)
-    assert eng.train(inp, targ) == 800
-    assert ora.train(inp, targ) == 800
-    del inp, targ
-    cv_tol, alpha_tol, w_tol = (1e-4, 5e-4, 2e-3) if beta >= 1.0 else (3e-4, 5e-2, 0.2)
     cin, ctarg = synth.make_frames(3000, 257, 11, seed=77)
+    eng = pkg.BPGpu(synth.DEFAULT_SEED, 0, ls, B, *HP, ws, bs, beta, ml)
+    assert eng.train(inp, targ) == 800
+
+    def oracle_run(split):
+        pyoracle.set_gemm_split(split)
+        try:
+            o = pyoracle.OracleNet(ls, B, *HP, beta, ml, ws, bs)
+            assert o.train(inp, targ) == 800
+            r = {"sq": o.cv_sqerr(cin, ctarg), "ab": o.cv_abserr(cin, ctarg),
+                 "ll": o.cv_loglik(cin, ctarg) if ml else 0.0, "alpha": o.tensor("scalefactor").copy(), "w": o.get_weights()[0]}
+            o.close()
+            return r
+        finally:
+            pyoracle.set_gemm_split(1)
+
+    ora = oracle_run(1)
     sq, ab, ll = eng.cv_all(cin, ctarg)
-    osq, oab = ora.cv_sqerr(cin, ctarg), ora.cv_abserr(cin, ctarg)
-    print("epoch horizon ml=%d beta=%.1f: sqerr %.6g vs %.6g (%.1e)  abserr %.6g vs %.6g (%.1e)" %
-          (ml, beta, sq, osq, abs(sq - osq) / abs(osq), ab, oab, abs(ab - oab) / abs(oab)))
-    assert abs(sq - osq) <= cv_tol * abs(osq)
-    assert abs(ab - oab) <= cv_tol * abs(oab)
-    if ml:
-        oll = ora.cv_loglik(cin, ctarg)
-        da = relmax(eng.scalefactor(), ora.tensor("scalefactor"))
-        print("   loglik %.6g vs %.6g (%.1e)  alpha relmax %.1e" % (ll, oll, abs(ll - oll) / abs(oll), da))
-        assert abs(ll - oll) <= cv_tol * abs(oll)
-        assert da < alpha_tol
-    we, be = eng.returnWeights()
-    wo, bo = ora.get_weights()
-    for l in range(4):
-        print("   layer %d: weights relmax %.1e relrms %.1e  bias relmax %.1e" %
-              (l + 1, relmax(we[l], wo[l]), relrms(we[l], wo[l]), relmax(be[l], bo[l])))
-        assert relmax(we[l], wo[l]) < w_tol, l
+    hip = {"sq": sq, "ab": ab, "ll": ll if ml else 0.0, "alpha": eng.scalefactor(), "w": eng.returnWeights()[0]}
+
+    def dist(a, b):
+        d = {k: abs(a[k] - b[k]) / max(abs(b[k]), 1e-30) for k in ("sq", "ab", "ll")}
+        d["alpha"] = relrms(a["alpha"], b["alpha"]) if ml else 0.0
+        d["alpha_max"] = relmax(a["alpha"], b["alpha"]) if ml else 0.0
+        d["w"] = max(relrms(x, y) for x, y in zip(a["w"], b["w"]))
+        d["w_max"] = max(relmax(x, y) for x, y in zip(a["w"], b["w"]))
+        return d
+
+    d_hip = dist(hip, ora)
+    print("epoch horizon ml=%d beta=%.1f: HIP vs oracle: sqerr %.1e abserr %.1e loglik %.1e | alpha relrms %.1e relmax %.1e | "
+          "weights relrms %.1e relmax %.1e" % (ml, beta, d_hip["sq"], d_hip["ab"], d_hip["ll"], d_hip["alpha"],
+                                               d_hip["alpha_max"], d_hip["w"], d_hip["w_max"]))
+    if beta >= 1.0:
+        assert d_hip["sq"] <= 1e-4 and d_hip["ab"] <= 1e-4 and d_hip["ll"] <= 1e-4
+        assert d_hip["alpha_max"] < 5e-4 and d_hip["w_max"] < 2e-3
+    else:
+        K_TWIN = 4.0
+        twins = [dist(oracle_run(sp), ora) for sp in (4, 7)]
+        yard = {k: max(t[k] for t in twins) for k in twins[0]}
+        for sp, t in zip((4, 7), twins):
+            print("   oracle order twin (split %d) vs oracle: sqerr %.1e abserr %.1e loglik %.1e | alpha relrms %.1e relmax %.1e | "
+                  "weights relrms %.1e relmax %.1e" % (sp, t["sq"], t["ab"], t["ll"], t["alpha"], t["alpha_max"], t["w"], t["w_max"]))
+        for k in ("sq", "ab", "ll", "alpha", "w"):
+            assert d_hip[k] <= K_TWIN * yard[k], (k, d_hip[k], yard[k])
+        # and the absolute level stays where r02 measured it (1e-4 / 4e-5 / 4e-5): an order of magnitude of slack
+        assert d_hip["sq"] <= 1e-3 and d_hip["ab"] <= 1e-3 and d_hip["ll"] <= 1e-3
     # the training loss has actually moved (the comparison is not between two untrained nets)
     assert sq / (3000 * 257) < 0.9
     eng.close()
-    ora.close()
 
 
 @pytest.mark.parametrize("ml,beta", [(0, 2.0), (1, 1.2)])
