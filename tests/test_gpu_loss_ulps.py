@@ -61,8 +61,8 @@ def test_device_powf_and_expf_in_ulps(pkg, synth):
         d_dev, d_host, d_dh = ulp_dist(dev, exact), ulp_dist(host, exact[:20000]), ulp_dist(dev[:20000], host)
         report.append((y, int(d_dev.max()), float((d_dev > 0).mean()), int(d_host.max()), float((d_host > 0).mean()),
                        int(d_dh.max()), float((d_dh > 0).mean())))
-        assert d_dev.max() <= 2, (y, d_dev.max())        # ocml powf: within 2 ulp of the correctly rounded value
-        assert d_host.max() <= 1, (y, d_host.max())      # glibc powf: within 1 ulp
+        assert d_dev.max() <= 2, (y, d_dev.max())        # ocml powf: measured 1 ulp max, 11-23 % of the values 1 ulp off
+        assert d_host.max() <= 1, (y, d_host.max())      # glibc powf: measured correctly rounded in 99.9 % of the cases
     for r in report:
         print("powf(x, %+.4f): device vs exact max %d ulp (%.1f %% differ) | glibc vs exact max %d ulp (%.1f %%) | "
               "device vs glibc max %d ulp (%.1f %% differ)" % (r[0], r[1], 100 * r[2], r[3], 100 * r[4], r[5], 100 * r[6]))
@@ -108,12 +108,11 @@ def test_loss_chain_on_an_exactly_representable_output_layer(pkg, pyoracle, beta
     print("beta %.1f %s: dEdX_L max %d ulp (%.1f %% of elements differ, mean %.2f ulp) | alpha max %d ulp (%.1f %% differ)"
           % (beta, "k_loss_ml" if fused else "k_loss_err+k_loss_grad", dg.max(), 100 * (dg > 0).mean(), dg.mean(), da.max(),
              100 * (da > 0).mean()))
-    if beta == 2.0:
-        # |e|^2 and |e|^1 .. powf(x, 2) and powf(x, 1) are exact in both libraries; alpha = powf(v, 0.5), alpha^2
-        assert da.max() <= 1 and dg.max() <= 4
-    else:
-        # every element's gradient is sgn(e) |e|^(beta-1) beta / alpha^beta / n: three powf results (each within
-        # 2 ulp of exact on the device, 1 ulp in glibc) and, through alpha, the sum of 128 more
-        assert da.max() <= 4 and dg.max() <= 12
+    # Measured r03 (MI355X, ROCm 7.2): dEdX_L max 5-6 ulp, mean 0.7-1.0 ulp, about half of the elements differ at all;
+    # alpha max 1 (beta 2) .. 3 ulp.  Every element's gradient is sgn(e) |e|^(beta-1) beta / alpha^beta / n: three powf
+    # results (each within 1 ulp of exact on the device, correctly rounded in 99.9 % of the cases by glibc) and, through
+    # alpha, the sum of 128 more.  Note powf(x, 2) is NOT x*x on the device (1 ulp off in 23 % of the cases), so beta = 2
+    # with MLflag = 1 is no exception; MLflag = 0 with beta = 2 takes powf(x, 1) = x and is bit-exact.
+    assert da.max() <= 4 and dg.max() <= 12 and dg.mean() <= 1.5
     eng.close()
     ora.close()
