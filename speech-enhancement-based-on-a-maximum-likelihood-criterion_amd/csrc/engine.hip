@@ -1964,6 +1964,21 @@ int mlggd_comm_init(mlggd_handle e, const void *id, int world_size, int rank) {
     if (e->comm) return fail(MLGGD_ERR_STATE, "communicator already initialised");
     if (e->cfg.dropoutflag == 1 && world_size > 1)
         return fail(MLGGD_ERR_ARG, "dropout is not supported on the data-parallel path");
+    // the exchange mode first: a request the shape rules out must fail BEFORE a communicator exists (every rank takes
+    // the same branch, so nobody is left waiting inside ncclCommInitRank)
+    int mode;
+    {
+        const char *m = getenv("MLGGD_DP_MODE");  // "gather" | "shard" | "allreduce"; default: gather where usable,
+        // sharded update from 6 ranks on (the W all-gather costs ~922/world us over world-1 links, the replicated
+        // update ~35 us per extra rank: DESIGN.md section 6 -- a cost model, not yet a measurement)
+        mode = gather_usable(e, world_size) ? (world_size >= 6 ? 2 : 1) : 0;
+        if (m && !strcmp(m, "allreduce")) mode = 0;
+        if (m && (!strcmp(m, "gather") || !strcmp(m, "shard"))) {
+            if (!gather_usable(e, world_size))
+                return fail(MLGGD_ERR_ARG, "MLGGD_DP_MODE=%s needs bunchsize %% 32 == 0 and world*bunchsize in {64,128,256,512,1024}", m);
+            mode = !strcmp(m, "shard") ? 2 : 1;
+        }
+    }
     CHK(rccl_load());
     HIPCHK(hipSetDevice(e->device));
     RcclUniqueId uid;
@@ -1971,20 +1986,8 @@ int mlggd_comm_init(mlggd_handle e, const void *id, int world_size, int rank) {
     NCCLCHK(g_rccl.CommInitRank(&e->comm, world_size, uid, rank));
     e->world = world_size;
     e->rank = rank;
+    e->dp_mode = mode;
     HIPCHK(hipStreamCreateWithFlags(&e->comm_stream, hipStreamNonBlocking));
-    {
-        const char *m = getenv("MLGGD_DP_MODE");  // "gather" (default where usable) | "allreduce"
-        // "gather" | "shard" | "allreduce"; default: gather where usable, sharded update from 6 ranks on
-        // (the W all-gather costs ~922/world us over world-1 links, the replicated update ~35 us per extra
-        // rank: DESIGN.md section 6)
-        e->dp_mode = gather_usable(e, world_size) ? (world_size >= 6 ? 2 : 1) : 0;
-        if (m && !strcmp(m, "allreduce")) e->dp_mode = 0;
-        if (m && (!strcmp(m, "gather") || !strcmp(m, "shard"))) {
-            if (!gather_usable(e, world_size))
-                return fail(MLGGD_ERR_ARG, "MLGGD_DP_MODE=%s needs bunchsize %% 32 == 0 and world*bunchsize in {64,128,256,512,1024}", m);
-            e->dp_mode = !strcmp(m, "shard") ? 2 : 1;
-        }
-    }
     if (e->dp_mode >= 1) {
         CHK(gather_alloc(e));
         return e->dp_mode == 2 ? shard_alloc(e) : MLGGD_OK;

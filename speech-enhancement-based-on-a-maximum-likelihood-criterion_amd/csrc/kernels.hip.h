@@ -2013,7 +2013,19 @@ __global__ __launch_bounds__(1024) void k_loss_ml(LossMlArgs A, int n_loss, Stag
             g = g * A.inv_n;                                                  // kernVecMulNum
         }
         A.dEdXt[(size_t)d * Bp + b] = g;
-        A.dEdX[(size_t)b * Dp + d] = g;
+        es[dl * (Bp + 1) + b] = g;  // this thread's own element: the row layout leaves below, 16 bytes at a time
+    }
+    // dEdX [frame][unit]: a frame's 8 units of this workgroup are 32 contiguous bytes -- two 16-byte stores per frame
+    // (2 * Bp per workgroup) instead of eight 4-byte stores each into a line of its own (8 * Bp)
+    __syncthreads();
+    for (int t = tid; t < 2 * Bp; t += 1024) {
+        const int b = t >> 1, h4 = (t & 1) * 4;
+        float4 v;
+        v.x = es[(h4 + 0) * (Bp + 1) + b];
+        v.y = es[(h4 + 1) * (Bp + 1) + b];
+        v.z = es[(h4 + 2) * (Bp + 1) + b];
+        v.w = es[(h4 + 3) * (Bp + 1) + b];
+        *reinterpret_cast<float4 *>(&A.dEdX[(size_t)b * Dp + d0 + h4]) = v;
     }
 }
 
