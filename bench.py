@@ -78,6 +78,10 @@ def parse_args(argv=None):
     ap.add_argument("--dry-launch", action="store_true",
                     help="start the ranks, rendezvous over gloo, report rank/world and exit before touching a GPU")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="self-launcher: seconds before the ranks are killed")
+    ap.add_argument("--stub-engine", action="store_true",
+                    help="TESTS ONLY (tests/test_bench_launcher.py): run the rank code over tests/bench_stub.py, a do-nothing "
+                         "stand-in for the package, so the multi-rank control flow is exercised on a machine without GPUs; "
+                         "the line it prints is marked and means nothing")
     return ap.parse_args(argv)
 
 
@@ -175,11 +179,21 @@ class Watchdog:
                 os._exit(rc)
 
 
+def claim_stdout():
+    """stdout is for ONE JSON line.  Libraries chat on it (gloo prints "[Gloo] Rank 0 is connected to ..." from C++), so
+    the rank keeps a private handle on the real stdout for that line and points fd 1 at stderr for everything else."""
+    sys.stdout.flush()
+    real = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    return real
+
+
 def dry_launch(rank, world, local_rank):
     """Rendezvous only: proves the launch path (children, env, gloo) without a GPU."""
     import datetime
     import torch
     import torch.distributed as dist
+    real_stdout = claim_stdout()
     wd = Watchdog(rank, world)
     # test hooks for tests/test_bench_launcher.py: a rank that dies early / a rank that never arrives
     if os.environ.get("MLGGD_BENCH_TEST_FAIL_RANK") == str(rank):
@@ -208,7 +222,7 @@ def dry_launch(rank, world, local_rank):
                           "distinct_pids": len({g["pid"] for g in got}),
                           "launched_by": "bench.py" if os.environ.get("MLGGD_BENCH_LAUNCHED") else
                                          ("external launcher" if world > 1 else "direct"),
-                          "gpu_touched": False}), flush=True)
+                          "gpu_touched": False}), file=real_stdout, flush=True)
     return 0
 
 
@@ -226,18 +240,28 @@ def rank_main(args):
         args.gpus = world
     if args.dry_launch:
         return dry_launch(rank, world, local_rank)
+    real_stdout = claim_stdout()
 
     import torch
     import torch.distributed as dist
 
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
-    if local_rank >= torch.cuda.device_count():
-        raise SystemExit("rank %d: LOCAL_RANK %d but only %d GPU(s) visible" % (rank, local_rank, torch.cuda.device_count()))
-    torch.cuda.set_device(local_rank)
-    wd = Watchdog(rank, world)
+    stub = args.stub_engine
+    if stub:  # tests only: no GPU, no package -- the control flow of the ranks and nothing else
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        pkg = importlib.import_module("bench_stub")
+        args.no_cpu_baseline = True
 
-    pkg = importlib.import_module(PKG)
+        def device_sync():
+            pass
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+        if local_rank >= torch.cuda.device_count():
+            raise SystemExit("rank %d: LOCAL_RANK %d but only %d GPU(s) visible" % (rank, local_rank, torch.cuda.device_count()))
+        torch.cuda.set_device(local_rank)
+        pkg = importlib.import_module(PKG)
+        device_sync = torch.cuda.synchronize
+    wd = Watchdog(rank, world)
     synth = importlib.import_module(PKG + ".synth")
     pkg.load()
 
@@ -248,11 +272,11 @@ def rank_main(args):
         dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=600))
 
     def barrier(what="barrier"):
-        torch.cuda.synchronize()
+        device_sync()
         if world > 1:
             last_coll["what"] = "gloo " + what
             dist.barrier()
-        torch.cuda.synchronize()
+        device_sync()
 
     def max_over_ranks(vals):
         if world == 1:
@@ -343,7 +367,7 @@ def rank_main(args):
         # deliver it -- with the reason -- and report success for THAT; otherwise nothing to print, status 3
         if rank == 0 and state["headline_done"]:
             out["incomplete"] = "watchdog: stuck in phase '%s' (%s)" % (phase, last_coll["what"])
-            print(json.dumps(out), flush=True)
+            print(json.dumps(out), file=real_stdout, flush=True)
             return 0
         return 0 if state["headline_done"] else 3
 
@@ -418,6 +442,8 @@ def rank_main(args):
                         "data parallel, include the wait for the 257-float all-reduce inside the loss bracket); "
                         "exposed = step wall time - compute; rank 0's view"}
 
+    if stub:
+        out["STUB_ENGINE"] = "tests only: no GPU was used, every number in this line is meaningless"
     out.update({
         "metric": "training frames/sec (%d-frame minibatch)" % B,
         "value": round(head["value"], 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
@@ -574,7 +600,7 @@ def rank_main(args):
         dist.destroy_process_group()
     wd.enter("done", 0)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=real_stdout, flush=True)
     return 0
 
 

@@ -21,8 +21,9 @@ def _env(**kw):
 
 
 def _json_line(stdout):
-    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, stdout
+    """stdout carries exactly ONE line, the JSON object -- no library chatter (gloo prints to stdout from C++)"""
+    lines = stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), stdout
     return json.loads(lines[0])
 
 
@@ -81,3 +82,41 @@ def test_watchdog_names_rank_and_phase():
                        env=_env(MLGGD_BENCH_TEST_HANG_RANK="1", MLGGD_BENCH_WATCHDOG_SCALE="0.02", MLGGD_BENCH_GRACE_S="2"))
     assert r.returncode == 3, (r.returncode, r.stderr)
     assert "bench watchdog: rank 1 of 2 stuck in phase 'test hang'" in r.stderr
+
+
+@pytest.mark.parametrize("form", ["self-launch", "torchrun"])
+def test_the_rank_code_runs_end_to_end_on_a_stub_engine(form):
+    """The world > 1 branches of bench.py (communicator hand-off over gloo, windows with max over ranks, ml_ggd leg, the
+    three exchange arms, dp_breakdown, teardown) first run for real on the driver's multi-GPU node; here they run over
+    tests/bench_stub.py so that a slip in that control flow shows on the CPU.  The numbers mean nothing."""
+    cmd = [BENCH, "--gpus", "2", "--steps", "4", "--warmup", "2", "--windows", "3", "--stub-engine"]
+    if form == "torchrun":
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port)] + cmd
+    r = subprocess.run([sys.executable] + cmd, capture_output=True, text=True, timeout=600, env=_env())
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _json_line(r.stdout)
+    assert "STUB_ENGINE" in d and d["n_gpus"] == 2 and d["steps"] == 4 and d["rccl_ranks"] == 2
+    assert d["rendezvous"] == "gloo" and d["config"]["dp_mode"] == "gather" and d["config"]["global_minibatch"] == 256
+    assert d["timing"]["windows"] == 3 and len(d["timing"]["window_ms"]) == 3
+    assert d["timing"]["window_ms_min"] <= d["ms_per_step"] * 4 <= d["timing"]["window_ms_max"]
+    assert abs(d["value"] - 2 * 128 * 4 / (d["ms_per_step"] * 4e-3)) <= 1e-3 * d["value"]
+    assert set(d["dp_arms"]) == {"allreduce", "gather", "shard"} and d["dp_arms"]["gather"]["same_as"] == "headline"
+    for arm in ("allreduce", "shard"):
+        assert d["dp_arms"][arm]["value"] > 0 and "dp_breakdown" in d["dp_arms"][arm]
+    assert d["dp_breakdown"]["compute_us_by_class"]["fwd"] == 10.0 and "ml_ggd" in d and "dp_breakdown" in d["ml_ggd"]
+    assert "incomplete" not in d
+
+
+def test_stub_engine_arm_the_shape_rules_out_is_reported_not_fatal():
+    # 2 x 96 frames: the factor exchange is unusable, the default is the all-reduce, the other two arms say why not
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "3", "--warmup", "1", "--windows", "2", "--bunch", "96",
+                        "--no-ml", "--stub-engine"], capture_output=True, text=True, timeout=600, env=_env())
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _json_line(r.stdout)
+    assert d["config"]["dp_mode"] == "allreduce" and d["dp_arms"]["allreduce"]["same_as"] == "headline"
+    assert "unavailable" in d["dp_arms"]["gather"] and "unavailable" in d["dp_arms"]["shard"]
