@@ -212,3 +212,35 @@ def test_errors_are_reported(pkg, synth):
     with pytest.raises(pkg.MlggdError):
         eng.train_resident(0, 8)  # nothing resident
     eng.close()
+
+
+def test_one_step_is_bit_exact_on_exactly_representable_data(pkg, pyoracle):
+    """With small-integer inputs, weights that are multiples of 1/8 and targets that are multiples of 1/4 every product
+    and partial sum of an MMSE step is exact in fp32, so GEMM summation order -- the one freedom cublasSgemm has
+    (TC/BP_GPU.cu:361,432) -- cannot matter, and ONE step must give the oracle's output, gradient,
+    momentum, weights and biases BIT FOR BIT: forward (k_fwd SLAB + k_loss_norm), dW + update (k_dwp with its fused
+    kernUpdatedelta / kernAccSum epilogue, TC/DevFunc.cu:490-507,427-443) and the bias path (kernAccSumrow order).
+    The shape -- 587 x 577 = 9 x 64 + 11 inputs, 9 x 64 + 1 outputs -- puts nearly empty edge tiles (11 valid rows,
+    1 valid column, the corner) next to full ones.  (Round 3 also ran this test against a variant of k_dwp that forms
+    those edge strips outside the tile walk: profiles/r03_dwp_edge_strips_ab.txt.)"""
+    K, N, B = 587, 577, 128
+    rng = np.random.default_rng(17)
+    W = (rng.integers(-4, 5, (K, N)) * 0.125).astype(np.float32)
+    b = (rng.integers(-8, 9, N) * 0.25).astype(np.float32)
+    x = rng.integers(-3, 4, (B, K)).astype(np.float32)
+    targ = (rng.integers(-8, 9, (B, N)) * 0.25).astype(np.float32)
+    eng = pkg.BPGpu(1, 0, [K, N], B, 0.1, 0.9, 1e-5, [W], [b], 2.0, 0)
+    ora = pyoracle.OracleNet([K, N], B, 0.1, 0.9, 1e-5, 2.0, 0, [W], [b])
+    assert eng.train(x, targ) == 1 and ora.train(x, targ) == 1
+    assert np.array_equal(eng.debug_tensor("out"), ora.tensor("out", rows=B))
+    assert np.array_equal(eng.debug_tensor("dedx", 1), ora.tensor("dedx", 1, rows=B))
+    dw_e, dw_o = eng.debug_tensor("delta_w", 1), ora.tensor("delta_w", 1)
+    bad = np.argwhere(dw_e != dw_o)
+    assert bad.size == 0, "first differing (k, n): %s of %d" % (bad[:5].tolist(), len(bad))
+    assert np.array_equal(eng.debug_tensor("delta_b", 1), ora.tensor("delta_b", 1))
+    (we,), (be,) = eng.returnWeights()
+    (wo,), (bo,) = ora.get_weights()
+    assert np.array_equal(we, wo) and np.array_equal(be, bo)
+    assert np.abs(dw_e[576:, :]).max() > 0 and np.abs(dw_e[:, 576]).max() > 0   # the edge rows / column did move
+    eng.close()
+    ora.close()

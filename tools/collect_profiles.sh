@@ -1,5 +1,5 @@
 set -x
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02prof; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03prof; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --no-cpu-baseline > $O/bench_under_rocprof.json 2>$O/trace.err &&
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-kernel-timing --no-ml > /dev/null 2>$O/f.err &&
