@@ -113,6 +113,38 @@ void exchange_id(int world, int rank, unsigned char id[MLGGD_UNIQUE_ID_BYTES]) {
 
 }  // namespace
 
+// Data-parallel runs only: RCCL collectives have no timeout, so a rank whose peer has died would sit in its next
+// collective for ever.  The main thread bumps g_progress at every chunk / phase; if it stays unchanged for
+// MLGGD_WATCHDOG_S seconds (default 900, 0 = off) this thread says where the rank was and ends the process with
+// status 3, so that a launcher (or the batch system) sees a failure instead of a hang.
+static std::atomic<long> g_progress{0};
+static std::atomic<const char *> g_phase{"start"};
+static void progress(const char *phase_name) {
+    g_phase = phase_name;
+    g_progress++;
+}
+static void watchdog_loop(int rank, int world, int timeout_s) {
+    long seen = -1;
+    double since = 0;
+    for (;;) {
+        std::this_thread::sleep_for(std::chrono::milliseconds(500));
+        const long now = g_progress.load();
+        if (now < 0) return;  // normal end of main
+        if (now != seen) {
+            seen = now;
+            since = 0;
+            continue;
+        }
+        since += 0.5;
+        if (since >= timeout_s) {
+            fprintf(stderr, "BPtrain watchdog: rank %d of %d made no progress for %d s in phase '%s' (step %ld); a peer has "
+                            "probably died inside a collective -- giving up\n", rank, world, timeout_s, g_phase.load(), seen);
+            fflush(stderr);
+            _exit(3);
+        }
+    }
+}
+
 // MLGGD_TIMING=1: wall-clock of the phases on stderr (where does an epoch of the executable go?)
 static double now_s() {
     struct timespec ts;
@@ -183,6 +215,13 @@ int main(int argc, char *argv[]) {
         } fetch_guard{fetch, slot};
         phase("pfile headers, chunk plan", t_phase);
 
+        std::thread watchdog;
+        const int wd_s = env_int("MLGGD_WATCHDOG_S", 900);
+        if (world > 1 && wd_s > 0) {
+            watchdog = std::thread(watchdog_loop, rank, world, wd_s);
+            watchdog.detach();
+        }
+        progress("engine + communicator");
         BP_GPU *net = new BP_GPU(p->init_randem_seed, device, io->numlayers, p->layersizes, p->bunchsize, p->lrate,
                                  p->momentum, p->weightcost, p->weights, p->bias, p->shapefactor, p->MLflag,
                                  p->dropoutflag, p->visible_omit, p->hid_omit);
@@ -196,8 +235,10 @@ int main(int argc, char *argv[]) {
         const int K0 = p->layersizes[0], D = p->layersizes[io->numlayers - 1], B = p->bunchsize;
         std::vector<float> loc_in, loc_targ;
         for (unsigned i = 0; i < io->total_chunks; i++) {
+            progress("waiting for a chunk");
             slot.wait(true);
             if (io->cur_chunk_samples < 0) break;
+            progress("training a chunk");
             io->logf("Starting chunk %d of %d containing %d samples.\n", i + 1, io->total_chunks, io->cur_chunk_samples);
             if (io->fp_log) fflush(io->fp_log);
             const int ns = io->cur_chunk_samples;
@@ -233,7 +274,9 @@ int main(int argc, char *argv[]) {
         }
         fetch.join();
         if (!fetch_error.empty()) throw IoError(fetch_error);
+        progress("final sync");
         net->sync();
+        progress("weights / CV");
         phase("training chunks", t_phase);
 
         io->logf("Total cost time: %.1f s.\n", (double)time(NULL) - t_start);  // BPtrain.cc:104-105
@@ -253,6 +296,7 @@ int main(int argc, char *argv[]) {
             for (unsigned i = 0; i < io->cv_total_chunks; i++) {
                 float sq = 0, ab = 0, ll = 0;
                 int n;
+                progress("cross validation");
                 if (frames) {
                     if (i == 0) io->reserve_frame_buffers(io->cv_plan);  // the device is idle here (net->sync() above)
                     n = io->Readchunk_frames_cv((int)i);
@@ -279,6 +323,7 @@ int main(int argc, char *argv[]) {
             phase("cross validation", t_phase);
         }
         printf("all finish!\n");
+        g_progress = -1000000;  // the watchdog leaves
         delete net;
         delete io;
         phase("teardown", t_phase);
