@@ -916,7 +916,6 @@ static int run_loss(mlggd_engine *e, const Bunch &bn, float nf, float inv_n, Col
                     const StageArgs &sa, int n_stage) {
     const int L = e->L, B = e->B, Bp = e->Bp, b_tiles = Bp / 32, ML = e->cfg.MLflag;
     ProfScope ps(e, KC_LOSS, 0);
-    const size_t lds = (size_t)(32 * (Bp + 1) + 32) * sizeof(float);               // k_colsum: 32 columns per workgroup
     const size_t lds_grad = (size_t)(LOSS_DT * (Bp + 1) + LOSS_DT) * sizeof(float);  // k_loss_grad: LOSS_DT columns
     const int n_loss = (e->Dp / LOSS_DT) * b_tiles;  // 8 (d) x 32 (b) elements per loss workgroup, one per thread
     if (ML != 1 && e->loss_fuse) {
@@ -952,8 +951,7 @@ static int run_loss(mlggd_engine *e, const Bunch &bn, float nf, float inv_n, Col
     if (ML == 1 && cs == CS_GIVEN) {
         colsum_in = e->colsum_tot;
     } else if (ML == 1 && cs != CS_LOCAL) {
-        CHK(ensure_lds(e, k_colsum, LOSS_LDS_MAX));
-        hipLaunchKernelGGL(k_colsum, dim3(e->Dp / 32), dim3(256), lds, e->stream, e->pT, B, Bp, e->colsum);
+        hipLaunchKernelGGL(k_colsum, dim3(e->Dp / 32), dim3(256), 0, e->stream, e->pT, B, Bp, e->colsum);  // wavefront reductions
         CHK(launch_check("k_colsum"));
         if (cs == CS_ACCUMULATE) {
             hipLaunchKernelGGL(k_accum, dim3(1), dim3(256), 0, e->stream, e->colsum_tot,

@@ -1784,7 +1784,7 @@ __global__ __launch_bounds__(256) void k_loss_err(LossErrArgs A, int n_loss, Sta
 
 // Per-dimension sum over the minibatch of |e|^beta in the reference's order (kernSumcol,
 // DevFunc.cu:167-185 <- BP_GPU.cu:416: one thread per column, rows added sequentially).
-// Shared by k_colsum (data-parallel path: the local sum is all-reduced; DT = 32) and k_loss_grad (DT = 8).
+// Used by k_loss_grad when it sums its own columns (one device, MLGGD_LOSS_FUSE=0; DT = 8).
 // rows: LDS [DT][Bp+1]; must be called by all 256 threads.
 template <int DT>
 __device__ __forceinline__ void colsum_tile(const float *__restrict__ pT, int d0, int B, int Bp, float *rows,
@@ -1812,12 +1812,26 @@ __device__ __forceinline__ void colsum_tile(const float *__restrict__ pT, int d0
     __syncthreads();
 }
 
+// Data-parallel path only: this rank's share of the per-dimension sum of |e|^beta, summed over the ranks by an
+// all-reduce right after -- so kernSumcol's sequential frame order (DevFunc.cu:167-185) cannot be kept anyway (the
+// parity definition of the data-parallel step is "the single-device step up to summation order"), and the
+// local part is a WAVEFRONT reduction (north_star): pT is [unit][frame] with the frames contiguous, so a wave reads a
+// dimension's frames as coalesced 256-byte rows (lane = frame), each lane adds its frames b = lane, lane + 64, ...,
+// and six cross-lane steps (DPP / ds_swizzle shuffles) finish the sum; 4 waves x 8 dimensions per workgroup, no LDS.
+// On ONE device the statistic stays in kernSumcol's order (k_loss_ml, colsum_tile).
 __global__ __launch_bounds__(256) void k_colsum(const float *__restrict__ pT, int B, int Bp,
                                                 float *__restrict__ colsum) {
-    extern __shared__ __attribute__((aligned(16))) float dyn[];
-    float *rows = dyn, *sums = dyn + 32 * (Bp + 1);
-    colsum_tile<32>(pT, blockIdx.x * 32, B, Bp, rows, sums);
-    if (threadIdx.x < 32) colsum[blockIdx.x * 32 + threadIdx.x] = sums[threadIdx.x];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const int d = blockIdx.x * 32 + wave * 8 + q;
+        const float *row = pT + (size_t)d * Bp;
+        float s = 0.0f;
+        for (int b = lane; b < B; b += 64) s += row[b];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (lane == 0) colsum[d] = s;
+    }
 }
 
 // ---------------------------------------------------------------------------------------
