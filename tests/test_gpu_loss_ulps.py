@@ -16,7 +16,6 @@ Measured (MI355X, ROCm 7.2, r03): see the bounds below and DESIGN.md section 2. 
 is UNPINNED against the reference (CUDA's powf is a third implementation; no reference output exists)."""
 import ctypes
 import ctypes.util
-import os
 
 import numpy as np
 import pytest
