@@ -84,10 +84,13 @@ def test_exchange_path_on_one_rank_communicator(pkg, pyoracle, synth, monkeypatc
     ws, bs = synth.make_weights(ls, seed=5)
     inp, targ = synth.make_frames(3 * B, 257, 3, seed=6)
     eng = pkg.BPGpu(1, 0, ls, B, *HP, ws, bs, beta, ml)
+    assert eng.comm_info() == (0, -1)                      # no communicator yet
     eng.comm_init(pkg.comm_unique_id(), 1, 0)
     assert eng.dp_mode() == {"allreduce": 1, "gather": 2, "shard": 3}[mode]
+    assert eng.comm_info() == (1, 0)                       # ncclCommCount / ncclCommUserRank: bench.py's `rccl_ranks`
     ora = pyoracle.OracleNet(ls, B, *HP, beta, ml, ws, bs)
     assert eng.train(inp, targ) == 3 and ora.train(inp, targ) == 3
+    assert eng.plan_count() <= 6                           # a handful of launch plans, however many steps
     we, be = eng.returnWeights()
     wo, bo = ora.get_weights()
     for l in range(3):

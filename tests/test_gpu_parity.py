@@ -214,6 +214,29 @@ def test_errors_are_reported(pkg, synth):
     eng.close()
 
 
+def test_refusals_leave_no_state_behind(pkg, synth, monkeypatch):
+    """mlggd_alloc_pinned_on validates the device (the BP_GPU.cu:17-21 message, not an out-of-memory error
+    from an IO thread) and leaves the caller's current device alone; an exchange mode the shape rules out is refused
+    BEFORE a communicator exists, so no rank can be left inside ncclCommInitRank."""
+    import ctypes as C
+    L = pkg.load()
+    p = C.c_void_p()
+    assert L.mlggd_alloc_pinned_on(99, 4096, C.byref(p)) != 0 and b"Not In Range" in L.mlggd_last_error()
+    assert L.mlggd_alloc_pinned_on(0, 4096, C.byref(p)) == 0 and p.value
+    assert L.mlggd_free_pinned(p) == 0
+    ls = [15, 8, 5]
+    ws, bs = synth.make_weights(ls, seed=1)
+    eng = pkg.BPGpu(1, 0, ls, 50, 0.1, 0.9, 0.0, ws, bs, 2.0, 0)   # 50 frames: not a multiple of 32
+    monkeypatch.setenv("MLGGD_DP_MODE", "gather")
+    with pytest.raises(pkg.MlggdError, match="MLGGD_DP_MODE=gather needs"):
+        eng.comm_init(pkg.comm_unique_id(), 1, 0)
+    assert eng.comm_info() == (0, -1) and eng.dp_mode() == 0          # nothing was created
+    monkeypatch.setenv("MLGGD_DP_MODE", "allreduce")
+    eng.comm_init(pkg.comm_unique_id(), 1, 0)                          # the same engine can still join
+    assert eng.comm_info() == (1, 0) and eng.dp_mode() == 1
+    eng.close()
+
+
 def test_one_step_is_bit_exact_on_exactly_representable_data(pkg, pyoracle):
     """With small-integer inputs, weights that are multiples of 1/8 and targets that are multiples of 1/4 every product
     and partial sum of an MMSE step is exact in fp32, so GEMM summation order -- the one freedom cublasSgemm has
