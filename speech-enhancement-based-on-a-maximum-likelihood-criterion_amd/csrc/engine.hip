@@ -107,6 +107,44 @@ static int rccl_load() {
             return fail(MLGGD_ERR_COMM, "%s failed: %s", #expr, g_rccl.GetErrorString(_r));        \
     } while (0)
 
+// ------------------------------------------------------------------ ROCTX ranges (loaded on demand)
+// MLGGD_ROCTX=1: the phases of every training step (forward, loss, backward, weight update, exchange) are bracketed
+// with roctxRangePush / Pop so that `rocprofv3 --marker-trace --kernel-trace` shows them around the kernels they
+// enqueue (the reference has no profiling hooks at all, BP_GPU.h:8-16 is an unused macro).
+// rocprofv3's own roctx library is tried first, the roctracer one second; off (and never loaded) by default.
+struct RoctxApi {
+    bool tried = false, on = false;
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+};
+static RoctxApi g_roctx;
+static void roctx_load() {
+    if (g_roctx.tried) return;
+    g_roctx.tried = true;
+    const char *v = getenv("MLGGD_ROCTX");
+    if (!v || !atoi(v)) return;
+    for (const char *n : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+        void *lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) continue;
+        g_roctx.push = (int (*)(const char *))dlsym(lib, "roctxRangePushA");
+        g_roctx.pop = (int (*)())dlsym(lib, "roctxRangePop");
+        if (g_roctx.push && g_roctx.pop) {
+            g_roctx.on = true;
+            return;
+        }
+    }
+    fprintf(stderr, "mlggd: MLGGD_ROCTX is set but no roctx library could be loaded\n");
+}
+struct RoctxRange {  // scope guard; a no-op unless MLGGD_ROCTX=1
+    bool on;
+    explicit RoctxRange(const char *name) : on(g_roctx.on) {
+        if (on) g_roctx.push(name);
+    }
+    ~RoctxRange() {
+        if (on) g_roctx.pop();
+    }
+};
+
 // ------------------------------------------------------------------ engine state
 enum KernelClass { KC_TRANSPOSE = 0, KC_FWD, KC_LOSS, KC_DX, KC_DW, KC_UPDATE, KC_COUNT };
 static const char *kKernelClassName[KC_COUNT] = {"transpose", "fwd", "loss", "dx", "dw", "update"};
@@ -1073,6 +1111,7 @@ static int run_step(mlggd_engine *e, int sample0, bool prestaged = false, const 
         sample0 += (e->world - 1) * B;  // the last emulated rank runs below
     }
     const Bunch bn = bunch_at(e, sample0);
+    RoctxRange step_range("mlggd step");
 
     // With the ML loss the hidden activations are sent AFTER the loss kernels: the 257-float all-reduce of the
     // loss statistic uses the same communicator, and collectives of one communicator run one after the other
@@ -1081,8 +1120,11 @@ static int run_step(mlggd_engine *e, int sample0, bool prestaged = false, const 
     // fine: replicated update on few ranks -- send every factor as soon as it exists (the links are the
     // bottleneck there, so they should never idle) and start the upper layers' dW while dEdX_1 still travels
     const bool fine = gather && e->dp_mode == 1 && e->dp_fine != 0;
-    CHK(run_forward(e, bn, B, true, prestaged,
-                    gather ? (GATHER_INPUT | (ML != 1 ? (fine ? GATHER_HIDDEN_EACH : GATHER_HIDDEN) : 0)) : 0));
+    {
+        RoctxRange r("forward");
+        CHK(run_forward(e, bn, B, true, prestaged,
+                        gather ? (GATHER_INPUT | (ML != 1 ? (fine ? GATHER_HIDDEN_EACH : GATHER_HIDDEN) : 0)) : 0));
+    }
     const float *in_rows = bunch_rows(e, bn);  // after run_forward: it may have switched in_bunch
     // input of the next step: Yt[0] is free from here on (forward_1 has been enqueued); frame-stream
     // rows go to the OTHER in_bunch buffer because this step's dW(1) still reads the current one
@@ -1093,7 +1135,11 @@ static int run_step(mlggd_engine *e, int sample0, bool prestaged = false, const 
         sa = stage_args(e, *next, B, in_bunch_other(e));
         n_stage = stage_blocks(e);
     }
-    CHK(run_loss(e, bn, nf, inv_n, !dp ? CS_LOCAL : e->fake_world ? CS_GIVEN : CS_ALLREDUCE, false, sa, n_stage));
+    {
+        RoctxRange r("loss (+ staging of the next minibatch)");
+        CHK(run_loss(e, bn, nf, inv_n, !dp ? CS_LOCAL : e->fake_world ? CS_GIVEN : CS_ALLREDUCE, false, sa, n_stage));
+    }
+    RoctxRange back_range("backward: dX, dW + update, exchange");
     if (gather && ML == 1 && L > 2) {
         CHK(gather_begin(e));
         for (int g = 1; g < L - 1; g++) CHK(gather_one(e, e->Y[g], e->Yall[g], (size_t)Bp * e->lsp[g]));
@@ -1289,6 +1335,7 @@ int mlggd_create(const mlggd_config *cfg, const float *const *weights, const flo
     if (const char *v = getenv("MLGGD_CV_DEVICE")) e->cv_device = atoi(v) ? 1 : 0;
     *out = e;  // so the caller can destroy on failure
 
+    roctx_load();
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&e->dw_stream, hipStreamNonBlocking));

@@ -408,3 +408,35 @@ def test_enhance_lps_tool_matches_decode_m_math(tmp_path):
             a = 1.0 / (1.0 + np.exp(-a))
     want = a / norm_inv + norm_mean                                    # decode.m:59-61
     assert np.abs(got - want).max() < 2e-4 * np.abs(want).max()
+
+
+def test_roctx_ranges_can_be_switched_on(pkg, synth):
+    """MLGGD_ROCTX=1 (read once per process, at the first mlggd_create): the step's phases are bracketed with
+    roctxRangePush / Pop for `rocprofv3 --marker-trace`; the library is dlopen'ed only then.  A child process trains two
+    steps with the ranges on and must reproduce this process's weights bit for bit."""
+    import subprocess
+    import sys
+    import zlib
+    code = (
+        "import importlib, sys, zlib, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "pkg = importlib.import_module(%r); synth = importlib.import_module(%r + '.synth')\n"
+        "ls, B = [257 * 3, 128, 96, 257], 64\n"
+        "ws, bs = synth.make_weights(ls, seed=5); inp, targ = synth.make_frames(2 * B, 257, 3, seed=6)\n"
+        "eng = pkg.BPGpu(1, 0, ls, B, 0.1, 0.9, 1e-5, ws, bs, 1.2, 1)\n"
+        "assert eng.train(inp, targ) == 2\n"
+        "w, b = eng.returnWeights(); eng.close()\n"
+        "print('CRC', zlib.crc32(b''.join(x.tobytes() for x in w + b)))\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), pkg.__name__, pkg.__name__)
+    env = dict(os.environ, MLGGD_ROCTX="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr
+    assert "no roctx library" not in r.stderr
+    ls, B = [257 * 3, 128, 96, 257], 64
+    ws, bs = synth.make_weights(ls, seed=5)
+    inp, targ = synth.make_frames(2 * B, 257, 3, seed=6)
+    eng = pkg.BPGpu(1, 0, ls, B, 0.1, 0.9, 1e-5, ws, bs, 1.2, 1)
+    assert eng.train(inp, targ) == 2
+    w, b = eng.returnWeights()
+    eng.close()
+    assert "CRC %d" % zlib.crc32(b"".join(x.tobytes() for x in w + b)) in r.stdout
