@@ -78,6 +78,10 @@ def parse_args(argv=None):
     ap.add_argument("--dry-launch", action="store_true",
                     help="start the ranks, rendezvous over gloo, report rank/world and exit before touching a GPU")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="self-launcher: seconds before the ranks are killed")
+    ap.add_argument("--rehearse-dp", action="store_true",
+                    help="one GPU: run the data-parallel code of this script -- RCCL communicator (of ONE rank), exchange "
+                         "path of the engine, ml_ggd leg, all exchange arms, dp_breakdown -- exactly as an N-rank run would; "
+                         "the line is marked `rehearsal` and its numbers are those of a 1-rank exchange, not a scaling result")
     ap.add_argument("--stub-engine", action="store_true",
                     help="TESTS ONLY (tests/test_bench_launcher.py): run the rank code over tests/bench_stub.py, a do-nothing "
                          "stand-in for the package, so the multi-rank control flow is exercised on a machine without GPUs; "
@@ -286,6 +290,7 @@ def rank_main(args):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return [float(x) for x in t]
 
+    dp = world > 1 or args.rehearse_dp  # the engine joins an RCCL communicator (of `world` ranks; 1 in a rehearsal)
     B = args.bunch
     ls = synth.baseline_layersizes(hidden=args.hidden, nhid=args.nhid)
     ml, beta = (1, 1.2) if args.loss == "ml" else (0, 2.0)
@@ -305,10 +310,11 @@ def rank_main(args):
             os.environ.pop("MLGGD_DP_MODE", None)
         wd.enter("engine create", 300)
         eng = pkg.BPGpu(synth.DEFAULT_SEED, local_rank, ls, B, 0.1, 0.9, 1e-5, ws, bs, beta_, ml_)
-        if world > 1:
+        if dp:
             wd.enter("RCCL communicator init (%s)" % (dp_mode or "auto"), 600, "gloo broadcast of the id, then ncclCommInitRank")
             uid = [pkg.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0)
+            if world > 1:
+                dist.broadcast_object_list(uid, src=0)
             eng.comm_init(uid[0], world, rank)
         eng.load_chunk(inp, targ)
         return eng
@@ -403,7 +409,7 @@ def rank_main(args):
             # HBM bytes per launch from rocprofv3 --pmc runs (profiles/README.md); they were collected on
             # the single-GPU plan (one launch for all layers, default shape) and only describe that one
             default_shape = (B == 128 and args.hidden == 2048 and args.nhid == 3)
-            if os.path.exists(pmc) and world == 1 and nl == 1 and default_shape:
+            if os.path.exists(pmc) and world == 1 and not dp and nl == 1 and default_shape:
                 try:
                     traffic = json.load(open(pmc)).get("k_dw", {}).get("hbm_bytes_per_launch")
                     traffic_source = ("profiles/pmc_traffic.json (committed; separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
@@ -444,6 +450,9 @@ def rank_main(args):
 
     if stub:
         out["STUB_ENGINE"] = "tests only: no GPU was used, every number in this line is meaningless"
+    if args.rehearse_dp and world == 1:
+        out["rehearsal"] = ("--rehearse-dp: the data-parallel path of bench.py and of the engine on ONE GPU through a 1-rank RCCL "
+                            "communicator; not a scaling measurement")
     out.update({
         "metric": "training frames/sec (%d-frame minibatch)" % B,
         "value": round(head["value"], 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
@@ -462,7 +471,7 @@ def rank_main(args):
                    "window": "[gloo barrier + device sync] t0 [--steps steps] [device sync] t1; nothing else inside"},
         "step_roofline_frac": round(head["value"] * fpf / (world * MFMA_F32_PEAK_TFLOPS * 1e12), 4),
         "roofline": roofline,
-        "rccl_ranks": eng.comm_info()[0] if world > 1 else 0,
+        "rccl_ranks": eng.comm_info()[0] if dp else 0,
         "rendezvous": "gloo" if world > 1 else None,
         "launched_by": "bench.py (child ranks)" if os.environ.get("MLGGD_BENCH_LAUNCHED") else
                        ("external launcher" if world > 1 else "direct"),
@@ -480,10 +489,10 @@ def rank_main(args):
                          "value": round(m_ml["value"], 1), "unit": "frames/s", "ms_per_step": round(m_ml["ms_per_step"], 5),
                          "window_ms_min": min(m_ml["window_ms"]), "window_ms_max": max(m_ml["window_ms"]),
                          "step_roofline_frac": round(m_ml["value"] * fpf / (world * MFMA_F32_PEAK_TFLOPS * 1e12), 4)}
-        if world > 1 and not args.no_kernel_timing:
+        if dp and not args.no_kernel_timing:
             out["ml_ggd"]["dp_breakdown"] = breakdown(eng, m_ml["ms_per_step"], "ml_ggd")
 
-    if world > 1 and not args.no_dp_arms:
+    if dp and not args.no_dp_arms:
         # The other gradient exchanges on the same ranks, same data, same windows: BASELINE.json names the all-reduce of
         # the weight gradients; the engine's default is the factor all-gather.  Every arm the
         # shape allows is reported so that one multi-GPU run decides the default from a measurement.
@@ -508,7 +517,7 @@ def rank_main(args):
             e2.close()
         out["dp_arms"] = arms
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not dp and not args.no_cpu_baseline:
         wd.enter("cpu baseline + loss_vs_oracle", 900)
         from oracle import pyoracle  # CPU oracle = the checker, timed here only as the reported CPU baseline
         ora = pyoracle.OracleNet(ls, B, 0.1, 0.9, 1e-5, beta, ml, ws, bs)

@@ -440,3 +440,29 @@ def test_roctx_ranges_can_be_switched_on(pkg, synth):
     w, b = eng.returnWeights()
     eng.close()
     assert "CRC %d" % zlib.crc32(b"".join(x.tobytes() for x in w + b)) in r.stdout
+
+
+def test_bench_rehearses_the_data_parallel_path_on_one_gpu():
+    """`bench.py --rehearse-dp`: the N-rank code of the benchmark -- RCCL communicator, the engine's exchange path, the
+    ml_ggd leg, every exchange arm with its dp_breakdown, teardown -- on ONE GPU through a 1-rank communicator, i.e.
+    everything of a multi-GPU run except the links.  (The launch / gloo side of it runs on the CPU:
+    tests/test_bench_launcher.py.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--rehearse-dp", "--steps", "5", "--warmup", "2",
+                        "--windows", "3"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert "rehearsal" in d and d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and "incomplete" not in d
+    assert d["config"]["dp_mode"] == "gather" and d["roofline"]["launches_timed"] == 64 * 2   # two dW launches per step
+    assert set(d["dp_arms"]) == {"allreduce", "gather", "shard"} and d["dp_arms"]["gather"]["same_as"] == "headline"
+    for arm in ("allreduce", "shard"):
+        a = d["dp_arms"][arm]
+        assert a["value"] > 1e5 and a["dp_breakdown"]["compute_us_by_class"]["dw"] > 0, (arm, a)
+    assert d["dp_arms"]["allreduce"]["dp_breakdown"]["compute_us_by_class"]["update"] > 0   # k_apply_update ran
+    assert d["ml_ggd"]["value"] > 1e5 and d["ml_ggd"]["dp_breakdown"]["compute_us_by_class"]["loss"] > 0
+    assert d["value"] > 1e5 and 0 < d["ms_per_step"] < 5
