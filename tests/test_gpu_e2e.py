@@ -459,8 +459,9 @@ def test_bench_rehearses_the_data_parallel_path_on_one_gpu():
     d = json.loads(lines[0])
     assert "rehearsal" in d and d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and "incomplete" not in d
     assert d["config"]["dp_mode"] == "gather" and d["roofline"]["launches_timed"] == 64 * 2   # two dW launches per step
-    assert set(d["dp_arms"]) == {"allreduce", "gather", "shard"} and d["dp_arms"]["gather"]["same_as"] == "headline"
-    for arm in ("allreduce", "shard"):
+    assert set(d["dp_arms"]) == {"allreduce", "gather", "shard", "gather_other_granularity"}
+    assert d["dp_arms"]["gather"]["same_as"] == "headline"
+    for arm in ("allreduce", "shard", "gather_other_granularity"):
         a = d["dp_arms"][arm]
         assert a["value"] > 1e5 and a["dp_breakdown"]["compute_us_by_class"]["dw"] > 0, (arm, a)
     assert d["dp_arms"]["allreduce"]["dp_breakdown"]["compute_us_by_class"]["update"] > 0   # k_apply_update ran
