@@ -223,6 +223,13 @@ struct mlggd_engine {
     // exists, and ev_layer[l] marks the moment both factors of layer l have arrived
     int dp_fine = 1;
     hipEvent_t ev_layer[MLGGD_MAXLAYER] = {0};
+    // Collectives that sit ON the step's critical path (the last factor dEdX_1 in front of the dW launch; W_1 in front
+    // of the next forward pass) are issued on the MAIN stream: a hop to the communication stream and back costs two
+    // event hand-offs of 6-10 us each plus ~5 us of queue bubble per record / wait (1-rank rehearsal, round 3:
+    // 30 us between dX_2 and k_dwp, 21 us between k_dwp and the next forward_1).  MLGGD_DP_MAINLINE=0: everything on
+    // the communication stream, as in round 2 (A/B).
+    int dp_mainline = 1;
+    bool comm_after_dw = false;  // the communication stream has already waited on an event recorded after the last dW launch
     RcclComm comm = nullptr;
     hipEvent_t ev_grad[MLGGD_MAXLAYER] = {0}, ev_red[MLGGD_MAXLAYER] = {0}, ev_bias = nullptr, ev_bias_red = nullptr;
 
@@ -493,9 +500,9 @@ static int run_dropout(mlggd_engine *e, int layer, const float *chunk_rows) {
 
 // prestaged: Yt[0] (and, for frame-stream chunks, the other in_bunch buffer) already hold this
 // bunch -- the previous training step staged it alongside its loss kernel
-static int gather_begin(mlggd_engine *e);
+static int gather_begin(mlggd_engine *e, bool already_ordered);
 static int gather_end(mlggd_engine *e);
-static int gather_one(mlggd_engine *e, const float *src, float *dst, size_t count);
+static int gather_one(mlggd_engine *e, const float *src, float *dst, size_t count, hipStream_t st);
 enum { GATHER_INPUT = 1, GATHER_HIDDEN = 2, GATHER_HIDDEN_EACH = 4 };  // data-parallel factor exchange issued from inside the forward pass
 
 static int run_forward(mlggd_engine *e, const Bunch &bn, int frames, bool training, bool prestaged = false,
@@ -507,10 +514,14 @@ static int run_forward(mlggd_engine *e, const Bunch &bn, int frames, bool traini
     }
     const float *in_rows = bunch_rows(e, bn);
     if (gather_flags & GATHER_INPUT) {  // the input rows can travel from the first microsecond of the step
-        CHK(gather_begin(e));
-        CHK(gather_one(e, in_rows, e->Yall[0], (size_t)e->Bp * e->lsp[0]));
+        // prestaged rows were written by the previous step's loss launch and Yall[0] was last read by its dW launch: if
+        // the communication stream has already waited on an event recorded after that launch (sharded update: the W
+        // gathers did), it needs no new event
+        CHK(gather_begin(e, prestaged && e->comm_after_dw && e->dp_mainline));
+        CHK(gather_one(e, in_rows, e->Yall[0], (size_t)e->Bp * e->lsp[0], nullptr));
         CHK(gather_end(e));
     }
+    e->comm_after_dw = false;
     const int b_tiles = e->Bp / 32;
     const bool drop = training && e->cfg.dropoutflag == 1;
     const bool cvscale = !training && e->cfg.dropoutflag == 1;
@@ -563,13 +574,13 @@ static int run_forward(mlggd_engine *e, const Bunch &bn, int frames, bool traini
         }
         if (drop && l != e->L - 1) CHK(run_dropout(e, l, nullptr));
         if ((gather_flags & GATHER_HIDDEN_EACH) && l < e->L - 1) {  // each hidden layer's activations at once
-            CHK(gather_begin(e));
-            CHK(gather_one(e, e->Y[l], e->Yall[l], (size_t)e->Bp * e->lsp[l]));
+            CHK(gather_begin(e, false));
+            CHK(gather_one(e, e->Y[l], e->Yall[l], (size_t)e->Bp * e->lsp[l], nullptr));
             CHK(gather_end(e));
         }
         if ((gather_flags & GATHER_HIDDEN) && l == e->L - 2) {  // all hidden activations exist: send them
-            CHK(gather_begin(e));                               // beside the output layer, the loss and dX
-            for (int g = 1; g < e->L - 1; g++) CHK(gather_one(e, e->Y[g], e->Yall[g], (size_t)e->Bp * e->lsp[g]));
+            CHK(gather_begin(e, false));                        // beside the output layer, the loss and dX
+            for (int g = 1; g < e->L - 1; g++) CHK(gather_one(e, e->Y[g], e->Yall[g], (size_t)e->Bp * e->lsp[g], nullptr));
             CHK(gather_end(e));
         }
     }
@@ -817,22 +828,26 @@ static int gather_alloc(mlggd_engine *e) {
     for (int l = 1; l < e->L; l++) HIPCHK(hipEventCreateWithFlags(&e->ev_layer[l], hipEventDisableTiming));
     if (const char *v = getenv("MLGGD_DP_FINE")) e->dp_fine = atoi(v);
     else e->dp_fine = e->world <= 5 ? 1 : 0;
+    if (const char *v = getenv("MLGGD_DP_MAINLINE")) e->dp_mainline = atoi(v);
     return MLGGD_OK;
 }
-// one rank's block -> every rank's slot r of dst (on the communication stream)
-static int gather_one(mlggd_engine *e, const float *src, float *dst, size_t count) {
+// one rank's block -> every rank's slot r of dst (on the communication stream, or on `st`)
+static int gather_one(mlggd_engine *e, const float *src, float *dst, size_t count, hipStream_t st = nullptr) {
+    if (!st) st = e->comm_stream;
     if (e->fake_world) {  // the other ranks' slots were filled by fake_world_prepass
-        HIPCHK(hipMemcpyAsync(dst + (size_t)e->rank * count, src, count * sizeof(float), hipMemcpyDeviceToDevice,
-                              e->comm_stream));
+        HIPCHK(hipMemcpyAsync(dst + (size_t)e->rank * count, src, count * sizeof(float), hipMemcpyDeviceToDevice, st));
         return MLGGD_OK;
     }
-    NCCLCHK(g_rccl.AllGather(src, dst, count, 7 /* ncclFloat32 */, e->comm, e->comm_stream));
+    NCCLCHK(g_rccl.AllGather(src, dst, count, 7 /* ncclFloat32 */, e->comm, st));
     return MLGGD_OK;
 }
-// the communication stream picks up everything the main stream has produced so far
-static int gather_begin(mlggd_engine *e) {
-    HIPCHK(hipEventRecord(e->ev_ready, e->stream));
-    HIPCHK(hipStreamWaitEvent(e->comm_stream, e->ev_ready, 0));
+// the communication stream picks up everything the main stream has produced so far (already_ordered: it has, through
+// an earlier event, and nothing newer is needed -- no record / wait, i.e. no bubble on the main queue)
+static int gather_begin(mlggd_engine *e, bool already_ordered = false) {
+    if (!already_ordered) {
+        HIPCHK(hipEventRecord(e->ev_ready, e->stream));
+        HIPCHK(hipStreamWaitEvent(e->comm_stream, e->ev_ready, 0));
+    }
     if (!e->fake_world) NCCLCHK(g_rccl.GroupStart());
     return MLGGD_OK;
 }
@@ -1152,6 +1167,7 @@ static int run_step(mlggd_engine *e, int sample0, bool prestaged = false, const 
     // that the all-reduce of layer l overlaps the rest of the backward pass)
     const bool merged = (!dp && !two && e->dw_merge && dwp_usable(e)) || gather;
     int pending_hi = L - 1;  // gather mode: dEdX_l for l in [l .. pending_hi] are final and not yet sent
+    bool mainline_done = false;  // the last factor group went out on the main stream: the dW launch needs no further event
     for (int l = L - 1; l >= 1; l--) {
         const int Kp = e->lsp[l - 1], Np = e->lsp[l];
         if (fine) {  // dEdX_l is final here (loss or dX_{l+1} has been enqueued): send it, layer l is then complete
@@ -1160,9 +1176,23 @@ static int run_step(mlggd_engine *e, int sample0, bool prestaged = false, const 
             CHK(gather_end(e));
             HIPCHK(hipEventRecord(e->ev_layer[l], e->comm_stream));
         } else if (gather && l <= 2) {  // two groups: everything down to dEdX_2 beside dX_2, dEdX_1 at the end
-            CHK(gather_begin(e));
-            for (int g = pending_hi; g >= l; g--) CHK(gather_one(e, e->dEdX[g], e->dEdXall[g], (size_t)Bp * e->lsp[g]));
-            CHK(gather_end(e));
+            if (l == 1 && e->dp_mainline && !two) {
+                // dEdX_1 is the one factor nothing can hide: the dW launch waits for it.  On the MAIN stream it costs
+                // its own time; by way of the communication stream it cost two event hand-offs more (30 us between
+                // dX_2 and k_dwp in the 1-rank rehearsal).  The earlier groups are awaited here, where they have
+                // long arrived.
+                HIPCHK(hipEventRecord(e->ev_gathered, e->comm_stream));
+                HIPCHK(hipStreamWaitEvent(e->stream, e->ev_gathered, 0));
+                if (!e->fake_world) NCCLCHK(g_rccl.GroupStart());
+                for (int g = pending_hi; g >= l; g--)
+                    CHK(gather_one(e, e->dEdX[g], e->dEdXall[g], (size_t)Bp * e->lsp[g], e->stream));
+                if (!e->fake_world) NCCLCHK(g_rccl.GroupEnd());
+                mainline_done = true;
+            } else {
+                CHK(gather_begin(e));
+                for (int g = pending_hi; g >= l; g--) CHK(gather_one(e, e->dEdX[g], e->dEdXall[g], (size_t)Bp * e->lsp[g]));
+                CHK(gather_end(e));
+            }
             pending_hi = l - 1;
         }
         if (l != 1) CHK(run_dx(e, l));
@@ -1184,8 +1214,10 @@ static int run_step(mlggd_engine *e, int sample0, bool prestaged = false, const 
         }
     }
     if (gather && e->dp_mode == 2) {
-        HIPCHK(hipEventRecord(e->ev_gathered, e->comm_stream));
-        HIPCHK(hipStreamWaitEvent(dws, e->ev_gathered, 0));
+        if (!mainline_done) {
+            HIPCHK(hipEventRecord(e->ev_gathered, e->comm_stream));
+            HIPCHK(hipStreamWaitEvent(dws, e->ev_gathered, 0));
+        }
         const int units = e->world * Bp / 64;
         if (e->fake_world) {
             // all virtual ranks in turn on this GPU: their row blocks are disjoint, so the union is the whole
@@ -1209,13 +1241,21 @@ static int run_step(mlggd_engine *e, int sample0, bool prestaged = false, const 
                 DwpJobs J = dwp_jobs_shard(e, nf, e->rank, 0, true);
                 if (J.total > 0) CHK(launch_dwp(e, J, true, dws, 1, units));
             }
+            // W_1 is what the next forward pass waits for first: its all-gather goes on the MAIN stream, right behind
+            // the update (no hand-off to the communication stream and back: 21 us between k_dwp and forward_1 in the
+            // 1-rank rehearsal); the upper layers' blocks travel on the communication stream beside forward_1
+            const bool w1_main = e->dp_mainline && !two;
             HIPCHK(hipEventRecord(e->ev_dw_done, dws));
             HIPCHK(hipStreamWaitEvent(e->comm_stream, e->ev_dw_done, 0));
+            e->comm_after_dw = true;
             for (int l = 1; l < L; l++) {  // layer 1 first: the next forward pass needs it first
                 const size_t count = (size_t)e->shard_rows[l] * 64 * e->lsp[l];
-                NCCLCHK(g_rccl.AllGather(e->W[l] + (size_t)e->rank * count, e->W[l], count, 7, e->comm, e->comm_stream));
-                HIPCHK(hipEventRecord(e->ev_W[l], e->comm_stream));
-                e->ev_W_pending[l] = true;
+                hipStream_t st = (l == 1 && w1_main) ? e->stream : e->comm_stream;
+                NCCLCHK(g_rccl.AllGather(e->W[l] + (size_t)e->rank * count, e->W[l], count, 7, e->comm, st));
+                if (st == e->comm_stream) {
+                    HIPCHK(hipEventRecord(e->ev_W[l], e->comm_stream));
+                    e->ev_W_pending[l] = true;
+                }
             }
         }
     } else if (fine) {
@@ -1231,8 +1271,10 @@ static int run_step(mlggd_engine *e, int sample0, bool prestaged = false, const 
         ProfScope ps(e, KC_DW, 1, dws);
         CHK(launch_dwp(e, dwp_jobs_global(e, nf, 1, 1), true, dws, 1, units));
     } else if (gather) {
-        HIPCHK(hipEventRecord(e->ev_gathered, e->comm_stream));
-        HIPCHK(hipStreamWaitEvent(dws, e->ev_gathered, 0));
+        if (!mainline_done) {
+            HIPCHK(hipEventRecord(e->ev_gathered, e->comm_stream));
+            HIPCHK(hipStreamWaitEvent(dws, e->ev_gathered, 0));
+        }
         ProfScope ps(e, KC_DW, 1, dws);
         CHK(launch_dwp(e, dwp_jobs_global(e, nf, L - 1, 1), true, dws, 1, e->world * Bp / 64));
     } else if (merged) {

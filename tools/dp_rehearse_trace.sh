@@ -1,0 +1,13 @@
+#!/bin/bash
+# kernel-trace timeline of a few steady-state steps of one exchange mode in the 1-rank rehearsal (see dp_rehearse_ab.sh)
+# usage: bash tools/dp_rehearse_trace.sh <mode> [extra env assignments...]
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; M=${1:-shard}; shift
+O=$R/gpurun_out/r03_dp_trace_$M; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+env "$@" true
+for kv in "$@"; do export "$kv"; done
+rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $O/trace -- python3 $R/bench.py --rehearse-dp --dp-mode $M --steps 20 --warmup 5 --windows 2 --no-ml --no-dp-arms --no-kernel-timing > $O/bench.json 2> $O/bench.err
+cd $R
+python3 tools/dp_trace_timeline.py $O/trace > $O/timeline.txt 2>&1
+rm -rf $O/trace
+tail -80 $O/timeline.txt
