@@ -243,6 +243,13 @@ struct mlggd_engine {
     size_t prof_used = 0;
     hipEvent_t *prof_attach = nullptr;  // event pair waiting to be attached to the next dW launch
     bool prof_attached = false;
+    // Data parallel: an event the communication stream is going to wait for can ride on the producing kernel's own
+    // dispatch packet (hipExtLaunchKernelGGL stop event = the packet's completion signal) instead of being a packet of
+    // its own behind it: a hipEventRecord on the main queue is a ~5 us bubble between two kernels (round 3, 1-rank
+    // rehearsal).  stop_ev_next: attach this event to the next GEMM launch; stop_ev_attached: it was.
+    hipEvent_t stop_ev_next = nullptr;
+    bool stop_ev_attached = false;
+    int dp_stopev = 1;  // MLGGD_DP_STOPEV=0: explicit records (A/B)
     double prof_flops = 0, prof_bytes = 0;
 
     // diagnostic in-kernel phase stamps (one launch of one (class, layer))
@@ -329,6 +336,9 @@ static void launch_timed(mlggd_engine *e, F kernel, dim3 grid, dim3 block, size_
     if (e->prof_attach && !e->prof_attached) {
         hipExtLaunchKernelGGL(kernel, grid, block, (std::uint32_t)lds, st, e->prof_attach[0], e->prof_attach[1], 0u, args...);
         e->prof_attached = true;
+    } else if (e->stop_ev_next && !e->stop_ev_attached) {
+        hipExtLaunchKernelGGL(kernel, grid, block, (std::uint32_t)lds, st, (hipEvent_t) nullptr, e->stop_ev_next, 0u, args...);
+        e->stop_ev_attached = true;
     } else {
         hipLaunchKernelGGL(kernel, grid, block, lds, st, args...);
     }
@@ -502,6 +512,8 @@ static int run_dropout(mlggd_engine *e, int layer, const float *chunk_rows) {
 // bunch -- the previous training step staged it alongside its loss kernel
 static int gather_begin(mlggd_engine *e, bool already_ordered);
 static int gather_end(mlggd_engine *e);
+static void gather_arm(mlggd_engine *e);
+static int gather_begin_armed(mlggd_engine *e);
 static int gather_one(mlggd_engine *e, const float *src, float *dst, size_t count, hipStream_t st);
 enum { GATHER_INPUT = 1, GATHER_HIDDEN = 2, GATHER_HIDDEN_EACH = 4 };  // data-parallel factor exchange issued from inside the forward pass
 
@@ -534,6 +546,9 @@ static int run_forward(mlggd_engine *e, const Bunch &bn, int frames, bool traini
             hipLaunchKernelGGL(k_scale, dim3(1024), dim3(256), 0, e->stream, e->W[l], (size_t)Kp * Np, keep);
         }
         {
+            // this layer's activations are sent right after the launch: the event rides on it
+            if (((gather_flags & GATHER_HIDDEN_EACH) && l < e->L - 1) || ((gather_flags & GATHER_HIDDEN) && l == e->L - 2))
+                gather_arm(e);
             ProfScope ps(e, KC_FWD, l);
             FwdArgs fa = fwd_args(e, l, e->Y[l]);
             if (l != e->L - 1) {
@@ -574,12 +589,12 @@ static int run_forward(mlggd_engine *e, const Bunch &bn, int frames, bool traini
         }
         if (drop && l != e->L - 1) CHK(run_dropout(e, l, nullptr));
         if ((gather_flags & GATHER_HIDDEN_EACH) && l < e->L - 1) {  // each hidden layer's activations at once
-            CHK(gather_begin(e, false));
+            CHK(gather_begin_armed(e));
             CHK(gather_one(e, e->Y[l], e->Yall[l], (size_t)e->Bp * e->lsp[l], nullptr));
             CHK(gather_end(e));
         }
         if ((gather_flags & GATHER_HIDDEN) && l == e->L - 2) {  // all hidden activations exist: send them
-            CHK(gather_begin(e, false));                        // beside the output layer, the loss and dX
+            CHK(gather_begin_armed(e));                         // beside the output layer, the loss and dX
             for (int g = 1; g < e->L - 1; g++) CHK(gather_one(e, e->Y[g], e->Yall[g], (size_t)e->Bp * e->lsp[g], nullptr));
             CHK(gather_end(e));
         }
@@ -829,6 +844,7 @@ static int gather_alloc(mlggd_engine *e) {
     if (const char *v = getenv("MLGGD_DP_FINE")) e->dp_fine = atoi(v);
     else e->dp_fine = e->world <= 5 ? 1 : 0;
     if (const char *v = getenv("MLGGD_DP_MAINLINE")) e->dp_mainline = atoi(v);
+    if (const char *v = getenv("MLGGD_DP_STOPEV")) e->dp_stopev = atoi(v);
     return MLGGD_OK;
 }
 // one rank's block -> every rank's slot r of dst (on the communication stream, or on `st`)
@@ -853,6 +869,27 @@ static int gather_begin(mlggd_engine *e, bool already_ordered = false) {
 }
 static int gather_end(mlggd_engine *e) {
     if (!e->fake_world) NCCLCHK(g_rccl.GroupEnd());
+    return MLGGD_OK;
+}
+// The next GEMM launch on the main stream produces what the communication stream is going to send: let ev_ready ride
+// on that launch (see stop_ev_next).  gather_begin_armed() then only records if the launch could not take the event
+// (a profiling pass owns the launch's event slots, or no GEMM launch came).
+static void arm_stop(mlggd_engine *e, hipEvent_t ev) {
+    if (!e->dp_stopev) return;
+    e->stop_ev_next = ev;
+    e->stop_ev_attached = false;
+}
+static bool take_stop(mlggd_engine *e) {  // true: the armed event went out with a launch
+    const bool attached = e->stop_ev_next != nullptr && e->stop_ev_attached;
+    e->stop_ev_next = nullptr;
+    e->stop_ev_attached = false;
+    return attached;
+}
+static void gather_arm(mlggd_engine *e) { arm_stop(e, e->ev_ready); }
+static int gather_begin_armed(mlggd_engine *e) {
+    if (!take_stop(e)) HIPCHK(hipEventRecord(e->ev_ready, e->stream));
+    HIPCHK(hipStreamWaitEvent(e->comm_stream, e->ev_ready, 0));
+    if (!e->fake_world) NCCLCHK(g_rccl.GroupStart());
     return MLGGD_OK;
 }
 // ---- sharded update (dp_mode 2) --------------------------------------------------------------------
@@ -1171,7 +1208,7 @@ static int run_step(mlggd_engine *e, int sample0, bool prestaged = false, const 
     for (int l = L - 1; l >= 1; l--) {
         const int Kp = e->lsp[l - 1], Np = e->lsp[l];
         if (fine) {  // dEdX_l is final here (loss or dX_{l+1} has been enqueued): send it, layer l is then complete
-            CHK(gather_begin(e));
+            CHK(gather_begin_armed(e));  // the event rode on dX_{l+1}'s launch (armed below), else it is recorded here
             CHK(gather_one(e, e->dEdX[l], e->dEdXall[l], (size_t)Bp * e->lsp[l]));
             CHK(gather_end(e));
             HIPCHK(hipEventRecord(e->ev_layer[l], e->comm_stream));
@@ -1189,12 +1226,17 @@ static int run_step(mlggd_engine *e, int sample0, bool prestaged = false, const 
                 if (!e->fake_world) NCCLCHK(g_rccl.GroupEnd());
                 mainline_done = true;
             } else {
-                CHK(gather_begin(e));
+                CHK(gather_begin_armed(e));
                 for (int g = pending_hi; g >= l; g--) CHK(gather_one(e, e->dEdX[g], e->dEdXall[g], (size_t)Bp * e->lsp[g]));
                 CHK(gather_end(e));
             }
             pending_hi = l - 1;
         }
+        // dX_l produces dEdX_{l-1}; if the next iteration sends it (or a group ending with it) on the communication
+        // stream, the event that stream waits for rides on this launch
+        if (l != 1 && gather && !two &&
+            (fine || l - 1 == 2 || (l - 1 == 1 && !(e->dp_mainline))))
+            gather_arm(e);
         if (l != 1) CHK(run_dx(e, l));
         if (two) {  // dw(l) after dX(l): dEdX_l is final and W_l has been read (old weights)
             HIPCHK(hipEventRecord(e->ev_dx[l], e->stream));
@@ -1239,13 +1281,15 @@ static int run_step(mlggd_engine *e, int sample0, bool prestaged = false, const 
                 if (Jb.total > 0) CHK(launch_dwp(e, Jb, true, dws, 1, units));
                 ProfScope ps(e, KC_DW, 1, dws);
                 DwpJobs J = dwp_jobs_shard(e, nf, e->rank, 0, true);
+                if (!two) arm_stop(e, e->ev_dw_done);  // the event the W gathers wait for rides on this launch
                 if (J.total > 0) CHK(launch_dwp(e, J, true, dws, 1, units));
             }
+            const bool dw_done_attached = take_stop(e);
             // W_1 is what the next forward pass waits for first: its all-gather goes on the MAIN stream, right behind
             // the update (no hand-off to the communication stream and back: 21 us between k_dwp and forward_1 in the
             // 1-rank rehearsal); the upper layers' blocks travel on the communication stream beside forward_1
             const bool w1_main = e->dp_mainline && !two;
-            HIPCHK(hipEventRecord(e->ev_dw_done, dws));
+            if (!dw_done_attached) HIPCHK(hipEventRecord(e->ev_dw_done, dws));
             HIPCHK(hipStreamWaitEvent(e->comm_stream, e->ev_dw_done, 0));
             e->comm_after_dw = true;
             for (int l = 1; l < L; l++) {  // layer 1 first: the next forward pass needs it first
