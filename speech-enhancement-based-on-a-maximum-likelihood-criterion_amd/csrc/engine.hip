@@ -1243,9 +1243,10 @@ static int run_step(mlggd_engine *e, int sample0, bool prestaged = false, const 
             HIPCHK(hipStreamWaitEvent(dws, e->ev_dx[l], 0));
         }
         if (merged) continue;  // all layers' dW + update run as one launch after the last dX
+        if (dp && !gather && !two) arm_stop(e, e->ev_grad[l]);  // "G_l written" rides on the launch that writes it
         CHK(launch_dw_layer(e, l, in_rows, !dp, nf, dws));
         if (dp && !gather) {
-            HIPCHK(hipEventRecord(e->ev_grad[l], dws));
+            if (!take_stop(e)) HIPCHK(hipEventRecord(e->ev_grad[l], dws));
             HIPCHK(hipStreamWaitEvent(e->comm_stream, e->ev_grad[l], 0));
             if (e->fake_world) {  // sum over the emulated ranks: what the all-reduce delivers
                 if (e->world > 1) CHK(launch_accum(e->G[l], e->Gpre[l], e->G[l], (size_t)Kp * Np, e->comm_stream));
