@@ -100,6 +100,14 @@ def test_the_rank_code_runs_end_to_end_on_a_stub_engine(form):
     r = subprocess.run([sys.executable] + cmd, capture_output=True, text=True, timeout=600, env=_env())
     assert r.returncode == 0, r.stderr[-3000:]
     d = _json_line(r.stdout)
+    # the driver's contract for the line: every key it reads is there, with the fixed values where they are fixed
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["unit"] == "frames/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and d["warmup"] == 2
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in d["roofline"], k
     assert "STUB_ENGINE" in d and d["n_gpus"] == 2 and d["steps"] == 4 and d["rccl_ranks"] == 2
     assert d["rendezvous"] == "gloo" and d["config"]["dp_mode"] == "gather" and d["config"]["global_minibatch"] == 256
     assert d["timing"]["windows"] == 3 and len(d["timing"]["window_ms"]) == 3
