@@ -31,6 +31,7 @@
 
 #include "bp_gpu.h"
 #include "dp_launch.h"
+#include "prefetch.h"
 #include "trainer_io.h"
 
 using mlggd_host::Interface;
@@ -39,63 +40,11 @@ using mlggd_host::WorkPara;
 
 namespace {
 
-// Two-slot hand-off between the fetch thread and the trainer (waitSignal/setSignal,
-// Interface.cc:14-53, with a predicate loop instead of a single `if`).
-struct Slot {
-    std::mutex m;
-    std::condition_variable cv;
-    bool full = false;
-    void wait(bool want) {
-        std::unique_lock<std::mutex> lk(m);
-        cv.wait(lk, [&] { return full == want; });
-    }
-    void set(bool v) {
-        {
-            std::lock_guard<std::mutex> lk(m);
-            full = v;
-        }
-        cv.notify_all();
-    }
-};
+using mlggd_host::Slot;
 
-void swap_buffers(Interface *io, bool frames) {  // BPtrain.cc:25-32
-    WorkPara *p = io->para;
-    if (frames) {
-        std::swap(p->frames_in[0], p->frames_in[1]);
-        std::swap(p->frames_targ[0], p->frames_targ[1]);
-        std::swap(p->first_frame[0], p->first_frame[1]);
-        std::swap(p->chunk_frames[0], p->chunk_frames[1]);
-        io->frames_swapped();
-    } else {
-        std::swap(p->indata[0], p->indata[1]);
-        std::swap(p->targ[0], p->targ[1]);
-    }
-}
-
-// threadFetch, BPtrain.cc:15-54
 std::atomic<bool> g_stop_fetch{false};  // set when the trainer gives up before consuming every chunk
 int g_pinned_device = 0;                // device whose context owns the page-locked chunk buffers
 std::string g_pinned_error;             // engine's message when a page-locked allocation failed (fetch thread only)
-
-void fetch_loop(Interface *io, Slot *slot, std::string *error, bool frames) {
-    try {
-        if (frames) io->reserve_frame_buffers(io->train_plan);  // once, for the largest chunk: no re-allocation mid-epoch
-        for (unsigned i = 0; i < io->total_chunks && !g_stop_fetch; i++) {
-            const int n = frames ? io->Readchunk_frames(io->chunk_index[i]) : io->Readchunk(io->chunk_index[i]);
-            if (i > 0) slot->wait(false);                      // trainer done with indata[1]
-            if (g_stop_fetch) break;
-            io->cur_chunk_samples = n;
-            swap_buffers(io, frames);
-            slot->set(true);
-        }
-    } catch (const std::exception &e) {
-        *error = e.what();
-        // the reader only knows "no buffer"; the engine knows why (e.g. gpu_used= names no device)
-        if (!g_pinned_error.empty()) *error += ": " + g_pinned_error;
-        io->cur_chunk_samples = -1;
-        slot->set(true);
-    }
-}
 
 int env_int(const char *name, int dflt) {
     const char *v = getenv(name);
@@ -201,7 +150,7 @@ int main(int argc, char *argv[]) {
                     return q;
                 },
                 [](void *q) { mlggd_free_pinned(q); });
-        std::thread fetch(fetch_loop, io, &slot, &fetch_error, frames);
+        std::thread fetch(mlggd_host::fetch_loop, io, &slot, &fetch_error, frames, &g_stop_fetch, &g_pinned_error);
         struct FetchGuard {  // any exception from here on: stop and join the reader before unwinding
             std::thread &t;
             Slot &s;
