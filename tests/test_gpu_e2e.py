@@ -335,6 +335,15 @@ def test_bptrain_sigmoid_executable(pkg, pyoracle, tmp_path):
     cvlines = lambda t: [l for l in t.splitlines() if l.startswith("CV")]
     assert cvlines(open(tmp_path / "mlp.exp.log").read()) == cvlines(log)
 
+    # data parallel, a peer that never shows up: rank 0 of 2 sits in the id hand-off; the watchdog names rank and phase
+    # and ends the process with status 3 instead of leaving it blocked (RCCL collectives have no timeout)
+    kv3 = dict(kv, outwts_file=tmp_path / "mlp.dp.wts", log_file=tmp_path / "mlp.dp.log")
+    res = subprocess.run([exe] + ["%s=%s" % (k, v) for k, v in kv3.items()], capture_output=True, text=True, timeout=120,
+                         env=dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MLGGD_ID_FILE=str(tmp_path / "id"),
+                                  MLGGD_WATCHDOG_S="3", MLGGD_RENDEZVOUS_TIMEOUT="60"))
+    assert res.returncode == 3, (res.returncode, res.stderr[-500:])
+    assert "BPtrain watchdog: rank 0 of 2 made no progress for 3 s in phase 'engine + communicator'" in res.stderr
+
     # errors: message in the log, non-zero exit status
     kv["initwts_file"] = tmp_path / "missing.wts"
     kv["log_file"] = tmp_path / "err.log"
