@@ -142,6 +142,38 @@ def test_emulated_world_equals_one_device_with_the_global_bunch(pkg, pyoracle, s
     eng.close()
 
 
+@pytest.mark.parametrize("mode", ["gather", "shard", "allreduce"])
+@pytest.mark.parametrize("ls", [[96, 70], [75, 64, 33]])
+@pytest.mark.parametrize("ml,beta", [(0, 2.0), (1, 0.9)])
+def test_emulated_world_on_shallow_nets(pkg, pyoracle, synth, monkeypatch, ml, beta, ls, mode):
+    """The data-parallel step on nets with ONE and TWO weight layers (no hidden activations to exchange; one dX launch or
+    none; the last factor group is the only one), both factor-exchange granularities: 2 emulated ranks x 64 frames
+    against the oracle with bunchsize 128 (TC/BP_GPU.cu:308-440 with numlayers 2 and 3)."""
+    for fine in ("0", "1"):
+        monkeypatch.setenv("MLGGD_DP_FINE", fine)
+        world, B, steps = 2, 64, 3
+        ws, bs = synth.make_weights(ls, seed=18)
+        rng = np.random.default_rng(19)
+        bs = [rng.uniform(-0.1, 0.1, b.shape).astype(np.float32) for b in bs]
+        inp = rng.standard_normal((steps * world * B, ls[0]), dtype=np.float32)
+        targ = rng.standard_normal((steps * world * B, ls[-1]), dtype=np.float32)
+        eng = pkg.BPGpu(1, 0, ls, B, *HP, ws, bs, beta, ml)
+        eng.fake_world(world, sharded=mode == "shard", allreduce=mode == "allreduce")
+        ora = pyoracle.OracleNet(ls, world * B, *HP, beta, ml, ws, bs)
+        assert eng.train(inp, targ) == steps and ora.train(inp, targ) == steps
+        we, be = eng.returnWeights()
+        wo, bo = ora.get_weights()
+        for l in range(len(we)):
+            assert relmax(we[l], wo[l]) < 5e-5, (fine, l)
+            assert relmax(be[l], bo[l]) < 5e-5, (fine, l)
+        if ml:
+            assert relmax(eng.scalefactor(), ora.tensor("scalefactor")) < 1e-4
+        eng.close()
+        ora.close()
+        if mode != "gather":
+            break   # the granularity knob only exists for the replicated factor exchange
+
+
 @pytest.mark.parametrize("ml,beta", [(0, 2.0), (1, 1.2)])
 def test_frame_stream_chunks_equal_expanded_chunks_bitwise(pkg, synth, ml, beta):
     """rows gathered on the device from the raw frame stream == the host-expanded
