@@ -142,6 +142,43 @@ def test_emulated_world_equals_one_device_with_the_global_bunch(pkg, pyoracle, s
     eng.close()
 
 
+@pytest.mark.parametrize("ml,beta", [(0, 2.0), (1, 1.2)])
+@pytest.mark.parametrize("mode", ["gather", "shard", "allreduce"])
+def test_frame_stream_chunks_on_the_exchange_path(pkg, synth, monkeypatch, mode, ml, beta):
+    """What BPtrain_Sigmoid does on a data-parallel rank: frame-stream chunks (rows gathered on the device, the next
+    minibatch staged ahead, chunks enqueued without waiting) WITH a communicator.  Through a 1-rank RCCL communicator
+    the factor-exchange modes with the MMSE loss must reproduce the plain engine bit for bit (same kernels over the
+    same rows); with the ML loss the statistic is summed in another order (wavefront reduction + all-reduce instead of
+    kernSumcol's sequence) and the all-reduce mode applies its update in a separate pass: equal to rounding."""
+    monkeypatch.setenv("MLGGD_DP_MODE", mode)
+    dim, ctx, B, toff = 40, 5, 64, 2
+    ls = [dim * ctx, 128, 96, dim]
+    rng = np.random.default_rng(23)
+    nfr = 700
+    feat = rng.standard_normal((nfr, dim), dtype=np.float32)
+    targ = (0.5 * feat + 0.5 * rng.standard_normal((nfr, dim), dtype=np.float32)).astype(np.float32)
+    ws, bs = synth.make_weights(ls, seed=24)
+    firsts = [rng.permutation(nfr - ctx + 1)[:4 * B + 7].astype(np.int32) for _ in range(3)]   # three chunks, ragged tails
+    out = []
+    for with_comm in (False, True):
+        eng = pkg.BPGpu(1, 0, ls, B, *HP, ws, bs, beta, ml)
+        if with_comm:
+            eng.comm_init(pkg.comm_unique_id(), 1, 0)
+        for first in firsts:
+            assert eng.train_frames(feat, targ, first, ctx, toff, wait=False) == 4
+        eng.sync()
+        w, b = eng.returnWeights()
+        out.append((w + b, eng.scalefactor()))
+        eng.close()
+    for x, y in zip(out[0][0], out[1][0]):
+        if mode == "allreduce" or ml:
+            assert relmax(y, x) < 2e-5
+        else:
+            assert np.array_equal(x, y)
+    if ml:
+        assert relmax(out[1][1], out[0][1]) < 1e-5
+
+
 @pytest.mark.parametrize("mode", ["gather", "shard", "allreduce"])
 @pytest.mark.parametrize("ls", [[96, 70], [75, 64, 33]])
 @pytest.mark.parametrize("ml,beta", [(0, 2.0), (1, 0.9)])
