@@ -82,6 +82,8 @@ def parse_args(argv=None):
                     help="one GPU: run the data-parallel code of this script -- RCCL communicator (of ONE rank), exchange "
                          "path of the engine, ml_ggd leg, all exchange arms, dp_breakdown -- exactly as an N-rank run would; "
                          "the line is marked `rehearsal` and its numbers are those of a 1-rank exchange, not a scaling result")
+    ap.add_argument("--no-dp-rehearsal", action="store_true",
+                    help="N = 1: skip the short 1-rank-communicator leg (`dp_rehearsal_1rank`)")
     ap.add_argument("--stub-engine", action="store_true",
                     help="TESTS ONLY (tests/test_bench_launcher.py): run the rank code over tests/bench_stub.py, a do-nothing "
                          "stand-in for the package, so the multi-rank control flow is exercised on a machine without GPUs; "
@@ -300,8 +302,9 @@ def rank_main(args):
     fpf = flop_per_frame(ls)
     frames = args.steps * B * world
 
-    def make_engine(ml_, beta_, dp_mode):
+    def make_engine(ml_, beta_, dp_mode, comm=None):
         """An engine on this rank's GPU with the chunk resident; N > 1: joined to a fresh RCCL communicator."""
+        comm = dp if comm is None else comm
         if dp_mode and dp_mode != "auto":
             os.environ["MLGGD_DP_MODE"] = dp_mode
         elif "MLGGD_DP_MODE_USER" in os.environ:
@@ -310,7 +313,7 @@ def rank_main(args):
             os.environ.pop("MLGGD_DP_MODE", None)
         wd.enter("engine create", 300)
         eng = pkg.BPGpu(synth.DEFAULT_SEED, local_rank, ls, B, 0.1, 0.9, 1e-5, ws, bs, beta_, ml_)
-        if dp:
+        if comm:
             wd.enter("RCCL communicator init (%s)" % (dp_mode or "auto"), 600, "gloo broadcast of the id, then ncclCommInitRank")
             uid = [pkg.comm_unique_id() if rank == 0 else None]
             if world > 1:
@@ -532,6 +535,25 @@ def rank_main(args):
                 arms[arm]["dp_breakdown"] = breakdown(e2, m2["ms_per_step"], "dp arm " + arm)
             e2.close()
         out["dp_arms"] = arms
+
+    if world == 1 and not dp and not args.no_dp_rehearsal and not stub:
+        # What the data-parallel exchange path costs BEFORE any link time, measured in the driver's own single-GPU run:
+        # the same engine through a 1-rank RCCL communicator (which serves its collectives as device copies), per
+        # exchange mode.  Not a scaling result -- the floor under every multi-GPU step.
+        reh = {"what": "this workload through a 1-rank RCCL communicator: the exchange path's fixed cost without links; "
+                       "single-GPU step for comparison: ms_per_step above", "ms_per_step": {}}
+        try:
+            eng.close()
+            eng = None
+            for arm in ("gather", "shard", "allreduce"):
+                e2 = make_engine(ml, beta, arm, comm=True)
+                m2 = measure(e2, "1-rank rehearsal " + arm, 256)
+                reh["ms_per_step"][arm] = round(m2["ms_per_step"], 5)
+                reh.setdefault("window_ms", {})[arm] = [min(m2["window_ms"]), max(m2["window_ms"])]
+                e2.close()
+        except Exception as ex:  # noqa: BLE001 -- an optional leg must not cost the line
+            reh["error"] = str(ex)[:200]
+        out["dp_rehearsal_1rank"] = reh
 
     if rank == 0 and world == 1 and not dp and not args.no_cpu_baseline:
         wd.enter("cpu baseline + loss_vs_oracle", 900)

@@ -1425,7 +1425,11 @@ int mlggd_create(const mlggd_config *cfg, const float *const *weights, const flo
     roctx_load();
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&e->dw_stream, hipStreamNonBlocking));
+    // (the second compute stream only exists when MLGGD_TWO_STREAMS asks for it: every HIP stream takes one of the
+    // process's few hardware queues, and two streams of one engine that land on the SAME queue serialise -- round 3:
+    // the first communicator engine created after other engines had come and gone ran its step in 251 instead of
+    // 173 us because its communication stream shared a queue with its main stream)
+    if (e->two_streams) HIPCHK(hipStreamCreateWithFlags(&e->dw_stream, hipStreamNonBlocking));
     for (int l = 0; l < e->L; l++) HIPCHK(hipEventCreateWithFlags(&e->ev_dx[l], hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&e->ev_upd, hipEventDisableTiming));
     HIPCHK(hipEventCreate(&e->ev_t0));
@@ -2080,6 +2084,55 @@ static int allreduce_alloc(mlggd_engine *e) {
     return MLGGD_OK;
 }
 
+// A stream of its own is only worth having if it does NOT share a hardware queue with the engine's main stream: the
+// HIP runtime multiplexes streams onto a few hardware queues (by reference count, so the mapping depends on every
+// stream the process has created and destroyed before), and two streams on one queue serialise.  Round 3, 1-rank
+// rehearsal: the first communicator engine created after other engines had come and gone ran its step in 251 instead
+// of 173 us for exactly that reason.  (Stream priorities are no way out: a high-priority communication stream made the
+// first engine of a process run at 770 us per step.)  So the stream is PROBED: a 300 us spin kernel on the main stream,
+// an empty kernel on the candidate; the candidate is kept if its kernel finishes while the spin is still running.
+// Rejected candidates are destroyed only afterwards, so that each new one lands on another queue.
+static int create_concurrent_stream(mlggd_engine *e, hipStream_t *out, const char *what) {
+    hipEvent_t ev_main = nullptr, ev_cand = nullptr;
+    HIPCHK(hipEventCreateWithFlags(&ev_main, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&ev_cand, hipEventDisableTiming));
+    std::vector<hipStream_t> rejected;
+    hipStream_t keep = nullptr;
+    int rc = MLGGD_OK, tries = 0;
+    static const bool verbose = getenv("MLGGD_VERBOSE") != nullptr;
+    for (; tries < 8 && !keep && rc == MLGGD_OK; tries++) {
+        hipStream_t cand = nullptr;
+        if (hipStreamCreateWithFlags(&cand, hipStreamNonBlocking) != hipSuccess) {
+            rc = fail(MLGGD_ERR_DEVICE, "cannot create the %s stream", what);
+            break;
+        }
+        hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, e->stream, 30000ll);  // 300 us of the 100 MHz wall clock
+        hipEventRecord(ev_main, e->stream);
+        hipLaunchKernelGGL(k_nop, dim3(1), dim3(64), 0, cand);
+        hipEventRecord(ev_cand, cand);
+        hipEventSynchronize(ev_cand);
+        const bool concurrent = hipEventQuery(ev_main) == hipErrorNotReady;
+        hipStreamSynchronize(e->stream);
+        if (hipGetLastError() != hipSuccess) rc = fail(MLGGD_ERR_DEVICE, "probing the %s stream failed", what);
+        if (concurrent) keep = cand;
+        else rejected.push_back(cand);
+    }
+    if (!keep && !rejected.empty()) {  // no concurrent queue to be had: correct anyway, only slower
+        keep = rejected.back();
+        rejected.pop_back();
+        fprintf(stderr, "mlggd: the %s stream shares a hardware queue with the main stream (no free queue after %d tries)\n",
+                what, tries);
+    } else if (verbose) {
+        fprintf(stderr, "mlggd: %s stream found after %d candidate(s)\n", what, tries);
+    }
+    for (hipStream_t r : rejected) hipStreamDestroy(r);
+    hipEventDestroy(ev_main);
+    hipEventDestroy(ev_cand);
+    *out = keep;
+    return rc;
+}
+static int create_comm_stream(mlggd_engine *e) { return create_concurrent_stream(e, &e->comm_stream, "communication"); }
+
 int mlggd_comm_unique_id(void *id) {
     if (!id) return fail(MLGGD_ERR_ARG, "id is NULL");
     CHK(rccl_load());
@@ -2119,7 +2172,7 @@ int mlggd_comm_init(mlggd_handle e, const void *id, int world_size, int rank) {
     e->world = world_size;
     e->rank = rank;
     e->dp_mode = mode;
-    HIPCHK(hipStreamCreateWithFlags(&e->comm_stream, hipStreamNonBlocking));
+    CHK(create_comm_stream(e));
     if (e->dp_mode >= 1) {
         CHK(gather_alloc(e));
         return e->dp_mode == 2 ? shard_alloc(e) : MLGGD_OK;
@@ -2147,7 +2200,7 @@ int mlggd_debug_fake_world(mlggd_handle e, int world_size, int mode) {
     e->rank = world_size - 1;  // the rank that takes the real exchange path; the others are emulated before it
     e->fake_world = true;
     e->dp_mode = mode == 2 ? 0 : mode == 1 ? 2 : 1;
-    HIPCHK(hipStreamCreateWithFlags(&e->comm_stream, hipStreamNonBlocking));
+    CHK(create_comm_stream(e));
     CHK(dev_alloc(e, &e->colsum_tot, e->Dp));
     if (mode == 2) {
         CHK(allreduce_alloc(e));

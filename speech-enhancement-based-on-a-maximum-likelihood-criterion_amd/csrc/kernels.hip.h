@@ -1607,6 +1607,17 @@ __global__ __launch_bounds__(256) void k_debug_math(int fn, const float *__restr
     out[i] = fn == 0 ? powf(v, y) : fn == 1 ? expf(v) : fn == 2 ? 1.0f / (1.0f + expf(-v)) : v / y;
 }
 
+// keeps one wave busy for `ticks` of the 100 MHz wall clock (bounded: at most `ticks` iterations of a loop whose
+// body takes longer than a tick): engine.hip create_concurrent_stream probes with it whether a new stream runs beside
+// the main stream or behind it
+__global__ __launch_bounds__(64) void k_spin(long long ticks) {
+    const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+    for (long long i = 0; i < ticks; i++) {
+        if ((long long)__builtin_amdgcn_s_memrealtime() - t0 >= ticks) break;
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
+
 // does nothing: the kernel mlggd_profile_overhead brackets to calibrate what a HIP-event bracket costs by itself
 __global__ __launch_bounds__(256) void k_nop() {}
 
