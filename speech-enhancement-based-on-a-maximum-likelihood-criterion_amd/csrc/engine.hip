@@ -1357,6 +1357,8 @@ static int run_step(mlggd_engine *e, int sample0, bool prestaged = false, const 
     return MLGGD_OK;
 }
 
+static int create_concurrent_stream(mlggd_engine *e, hipStream_t *out, const char *what);
+
 // ------------------------------------------------------------------ C-ABI
 extern "C" {
 
@@ -1639,7 +1641,7 @@ int mlggd_load_frames(mlggd_handle e, int n_frames, int fea_context, const float
                         first_frame[s] + fea_context, n_frames);
     HIPCHK(hipSetDevice(e->device));
     if (!e->copy_stream) {
-        HIPCHK(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+        CHK(create_concurrent_stream(e, &e->copy_stream, "upload"));  // must not queue behind the chunk's kernels
         for (auto &r : e->raw) HIPCHK(hipEventCreateWithFlags(&r.last_use, hipEventDisableTiming));
     }
     // the set that is NOT current: its last reader (two chunks ago) has finished or is about to; wait for it
