@@ -502,10 +502,10 @@ def rank_main(args):
         arms = {}
         eng.close()
         eng = None
-        # "gather_other_granularity": the factor exchange with the OTHER setting of MLGGD_DP_FINE than the default for
-        # this world size (1 = every factor sent the moment it exists + the dW launch split in two, default up to 5
-        # ranks; 0 = four grouped exchanges and one launch): an existing knob whose default is a cost model, so the
-        # first multi-GPU run measures both
+        # "gather_other_granularity": the factor exchange with the OTHER setting of MLGGD_DP_FINE than the one in force
+        # (0 = four grouped exchanges and one dW launch, the default; 1 = every factor sent the moment it exists + the
+        # dW launch split in two): the default rests on a 1-rank measurement and a link model, so the first multi-GPU
+        # run measures both
         fine_default = os.environ.get("MLGGD_DP_FINE")
         for arm in ("allreduce", "gather", "shard", "gather_other_granularity"):
             if arm == DP_MODE_NAME[mode]:
@@ -513,7 +513,7 @@ def rank_main(args):
                 continue
             other = arm == "gather_other_granularity"
             if other:
-                os.environ["MLGGD_DP_FINE"] = "1" if (fine_default == "0" or (fine_default is None and world > 5)) else "0"
+                os.environ["MLGGD_DP_FINE"] = "0" if fine_default == "1" else "1"
             try:
                 e2 = make_engine(ml, beta, "gather" if other else arm)
             except pkg.MlggdError as ex:  # the shape rules the factor exchange out (every rank takes this branch)
@@ -530,7 +530,7 @@ def rank_main(args):
                          "window_ms_min": min(m2["window_ms"]), "window_ms_max": max(m2["window_ms"]),
                          "dp_exchange": DP_EXCHANGE[e2.dp_mode()]}
             if other:
-                arms[arm]["MLGGD_DP_FINE"] = 1 if (fine_default == "0" or (fine_default is None and world > 5)) else 0
+                arms[arm]["MLGGD_DP_FINE"] = 0 if fine_default == "1" else 1
             if not args.no_kernel_timing:
                 arms[arm]["dp_breakdown"] = breakdown(e2, m2["ms_per_step"], "dp arm " + arm)
             e2.close()

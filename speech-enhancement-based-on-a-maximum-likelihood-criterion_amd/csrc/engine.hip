@@ -841,8 +841,14 @@ static int gather_alloc(mlggd_engine *e) {
     HIPCHK(hipEventCreateWithFlags(&e->ev_ready, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&e->ev_gathered, hipEventDisableTiming));
     for (int l = 1; l < e->L; l++) HIPCHK(hipEventCreateWithFlags(&e->ev_layer[l], hipEventDisableTiming));
+    // Default: the GROUPED factor exchange (four exchanges per step) at every world size.  Round 2 chose the
+    // fine-grained form (every factor sent the moment it exists, dW launch split in two) up to 5 ranks on a link model;
+    // round 3 measured what it costs before any link time -- +15 us of device time per step (seven more hand-offs
+    // between the streams) and twice the host enqueue time (143 vs 70 us per step, next to a 170 us device step) --
+    // against a modelled gain of ~20 us of hidden link time at 2 ranks.  MLGGD_DP_FINE=1 selects it; bench.py measures
+    // both forms in every multi-GPU run (dp_arms.gather_other_granularity).
     if (const char *v = getenv("MLGGD_DP_FINE")) e->dp_fine = atoi(v);
-    else e->dp_fine = e->world <= 5 ? 1 : 0;
+    else e->dp_fine = 0;
     if (const char *v = getenv("MLGGD_DP_MAINLINE")) e->dp_mainline = atoi(v);
     if (const char *v = getenv("MLGGD_DP_STOPEV")) e->dp_stopev = atoi(v);
     return MLGGD_OK;

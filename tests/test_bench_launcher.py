@@ -114,7 +114,7 @@ def test_the_rank_code_runs_end_to_end_on_a_stub_engine(form):
     assert d["timing"]["window_ms_min"] <= d["ms_per_step"] * 4 <= d["timing"]["window_ms_max"]
     assert abs(d["value"] - 2 * 128 * 4 / (d["ms_per_step"] * 4e-3)) <= 1e-3 * d["value"]
     assert set(d["dp_arms"]) == {"allreduce", "gather", "shard", "gather_other_granularity"}
-    assert d["dp_arms"]["gather"]["same_as"] == "headline" and d["dp_arms"]["gather_other_granularity"]["MLGGD_DP_FINE"] == 0
+    assert d["dp_arms"]["gather"]["same_as"] == "headline" and d["dp_arms"]["gather_other_granularity"]["MLGGD_DP_FINE"] == 1
     for arm in ("allreduce", "shard", "gather_other_granularity"):
         assert d["dp_arms"][arm]["value"] > 0 and "dp_breakdown" in d["dp_arms"][arm]
     assert d["dp_breakdown"]["compute_us_by_class"]["fwd"] == 10.0 and "ml_ggd" in d and "dp_breakdown" in d["ml_ggd"]

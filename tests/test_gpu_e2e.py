@@ -536,7 +536,7 @@ def test_bench_rehearses_the_data_parallel_path_on_one_gpu():
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert "rehearsal" in d and d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and "incomplete" not in d
-    assert d["config"]["dp_mode"] == "gather" and d["roofline"]["launches_timed"] == 64 * 2   # two dW launches per step
+    assert d["config"]["dp_mode"] == "gather" and d["roofline"]["launches_timed"] == 64   # one dW launch per step (grouped exchange)
     assert set(d["dp_arms"]) == {"allreduce", "gather", "shard", "gather_other_granularity"}
     assert d["dp_arms"]["gather"]["same_as"] == "headline"
     for arm in ("allreduce", "shard", "gather_other_granularity"):
