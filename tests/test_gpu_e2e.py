@@ -142,6 +142,31 @@ def test_emulated_world_equals_one_device_with_the_global_bunch(pkg, pyoracle, s
     eng.close()
 
 
+@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("ml,beta", [(0, 2.0), (1, 1.2)])
+def test_emulated_world_with_the_fine_grained_factor_exchange(pkg, pyoracle, synth, monkeypatch, ml, beta, world):
+    """MLGGD_DP_FINE=1 (no longer the default): every factor sent the moment it exists, the dW launch split in two
+    (layers L-1..2, then layer 1) -- same contract as test_emulated_world_equals_one_device_with_the_global_bunch."""
+    monkeypatch.setenv("MLGGD_DP_FINE", "1")
+    B, steps = 128, 2
+    ls = [40 * 5, 160, 96, 40]
+    ws, bs = synth.make_weights(ls, seed=8)
+    inp, targ = synth.make_frames(steps * world * B + 5, 40, 5, seed=10)
+    eng = pkg.BPGpu(1, 0, ls, B, *HP, ws, bs, beta, ml)
+    eng.fake_world(world)
+    assert eng.dp_mode() == 2
+    ora = pyoracle.OracleNet(ls, world * B, *HP, beta, ml, ws, bs)
+    assert eng.train(inp, targ) == steps and ora.train(inp, targ) == steps
+    we, be = eng.returnWeights()
+    wo, bo = ora.get_weights()
+    for l in range(len(we)):
+        assert relmax(we[l], wo[l]) < 2e-5, l
+        assert relmax(be[l], bo[l]) < 2e-5, l
+    if ml:
+        assert relmax(eng.scalefactor(), ora.tensor("scalefactor")) < 1e-5
+    eng.close()
+
+
 @pytest.mark.parametrize("ml,beta", [(0, 2.0), (1, 1.2)])
 @pytest.mark.parametrize("mode", ["gather", "shard", "allreduce"])
 def test_frame_stream_chunks_on_the_exchange_path(pkg, synth, monkeypatch, mode, ml, beta):
