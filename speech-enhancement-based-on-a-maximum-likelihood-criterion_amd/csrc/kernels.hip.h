@@ -1741,11 +1741,15 @@ __device__ __forceinline__ float slab_sum(const float *__restrict__ slab, size_t
 // the row-major dEdX are touched in 32-byte pieces (they are 0.13 MB per step).  Round 1 used 32 x 32 tiles with
 // four elements per thread: 36 workgroups whose threads each ran four slab sums and four powf one after the other
 // -- 8 us of pure latency for 33k elements; with 144 workgroups the chain is a quarter as long.
-// pow(x, 1.0f) is x itself for every float (IEEE 754 / C99 F.9.4.4), so the MMSE case (beta - 1 = 1) skips the
-// call: same bits, no powf on that path.
+// pow(x, 1.0f) is x itself and pow(x, 0.0f) is 1 for every float (IEEE 754-2008 9.2.1 / C99 F.9.4.4): the correctly
+// rounded results, which glibc's powf (the oracle) returns.  EVERY pow of the chain goes through pow_or_self, so at
+// the reference's shipped objective (MLflag = 1, shapefactor = 1, TC/finetune.pl:25-26) the chain holds no libm call
+// at all -- p = |e|, alpha = v2, alpha^beta = alpha, |e|^(beta-1) = 1 -- and is IEEE arithmetic in the reference's
+// order; the same for the MMSE case (beta - 1 = 1).  What ocml's powf itself returns for y = 1 and y = 0 is measured
+// in tests/test_gpu_loss_ulps.py.
 // ---------------------------------------------------------------------------------------
 constexpr int LOSS_DT = 8;  // output units per loss workgroup
-__device__ __forceinline__ float pow_or_self(float x, float p) { return p == 1.0f ? x : powf(x, p); }
+__device__ __forceinline__ float pow_or_self(float x, float p) { return p == 1.0f ? x : p == 0.0f ? 1.0f : powf(x, p); }
 
 // Phase A:   out = bias + sum_s slab;  e = out - targ;  p = |e|^beta
 // kernerror, kernabsolutevalus, kernindex2 (DevFunc.cu:399-409,186-191,219-227 <- BP_GPU.cu:413-415).
@@ -1776,7 +1780,7 @@ __device__ __forceinline__ void loss_err_body(const LossErrArgs &A, const int bi
     float e = 0.0f, p = 0.0f;
     if (b < A.B && d < A.D) {
         e = x - targ[(size_t)(first ? first[b] + A.toff : b) * A.D + d];  // kernerror
-        if (A.want_pow) p = powf(fabsf(e), A.beta);                       // kernabsolutevalus + kernindex2
+        if (A.want_pow) p = pow_or_self(fabsf(e), A.beta);                      // kernabsolutevalus + kernindex2
     } else {
         x = 0.0f;
     }
@@ -1879,9 +1883,9 @@ __global__ __launch_bounds__(256) void k_loss_grad(const float *__restrict__ eT,
             if (d < D) {
                 const float v1 = sums[tid] / nf;            // kernDivide
                 const float v2 = v1 * beta;                 // kernVecMulNum
-                const float alpha = powf(v2, 1.0f / beta);  // kernindex2 with ppp = 1.0f/shapefactor
+                const float alpha = pow_or_self(v2, 1.0f / beta);  // kernindex2 with ppp = 1.0f/shapefactor
                 if (bt == 0) scalefactor[d] = alpha;
-                q = powf(alpha, beta);                      // pow(vec[j], alpha) in kernfunc2
+                q = pow_or_self(alpha, beta);                 // pow(vec[j], alpha) in kernfunc2
             }
             denom[tid] = q;
         }
@@ -1995,7 +1999,7 @@ __global__ __launch_bounds__(1024) void k_loss_ml(LossMlArgs A, int n_loss, Stag
         float e = 0.0f, p = 0.0f;
         if (b < B && d < D) {
             e = x - targ[(size_t)(first ? first[b] + A.toff : b) * D + d];  // kernerror
-            p = powf(fabsf(e), beta);                                       // kernabsolutevalus + kernindex2
+            p = pow_or_self(fabsf(e), beta);                                  // kernabsolutevalus + kernindex2
         } else {
             x = 0.0f;
         }
@@ -2021,9 +2025,9 @@ __global__ __launch_bounds__(1024) void k_loss_ml(LossMlArgs A, int n_loss, Stag
         if (d0 + tid < D) {
             const float v1 = s / A.nf;                  // kernDivide
             const float v2 = v1 * beta;                 // kernVecMulNum
-            const float alpha = powf(v2, 1.0f / beta);  // kernindex2 with ppp = 1.0f/shapefactor
+            const float alpha = pow_or_self(v2, 1.0f / beta);  // kernindex2 with ppp = 1.0f/shapefactor
             A.scalefactor[d0 + tid] = alpha;
-            q = powf(alpha, beta);                      // pow(vec[j], alpha) in kernfunc2
+            q = pow_or_self(alpha, beta);                 // pow(vec[j], alpha) in kernfunc2
         }
         denom[tid] = q;
     }
@@ -2120,7 +2124,7 @@ __global__ __launch_bounds__(256) void k_cv_reduce(CvArgs A) {
             const float t = tt[tx][dl];
             sq += (double)((x - t) * (x - t));   // BP_GPU.cu:211
             ab += (double)fabsf(x - t);           // BP_GPU.cu:246
-            if (A.alpha) ll += (double)powf(fabsf(t - x) / A.alpha[d], A.beta);  // BP_GPU.cu:295-296
+            if (A.alpha) ll += (double)pow_or_self(fabsf(t - x) / A.alpha[d], A.beta);  // BP_GPU.cu:295-296
         }
     }
 #pragma unroll

@@ -50,6 +50,18 @@ void BP_GPU::train(int n_frames, float *in, const float *targ) {
     if (rest > 0) printf("this bunch has only %d samples and is ignored.\n", rest);  // BP_GPU.cu:179
 }
 
+void BP_GPU::train_bunch_single(int n_frames, float *in, const float *targ) {
+    if (n_frames != bunchsize) {  // the engine's launch plan is built for one minibatch size (the reference's n_frames here is always bunchsize, BP_GPU.cu:175)
+        fprintf(stderr, "train_bunch_single: n_frames %d is not the bunchsize %d\n", n_frames, bunchsize);
+        printf("train_bunch_single: n_frames %d is not the bunchsize %d\n", n_frames, bunchsize);
+        exit(1);
+    }
+    int trained = 0;
+    check(mlggd_load_chunk(h_, n_frames, in, targ), "mlggd_load_chunk");
+    check(mlggd_train_resident(h_, 0, n_frames, &trained), "mlggd_train_resident");
+    check(mlggd_sync(h_), "mlggd_sync");
+}
+
 float BP_GPU::CrossValid(int n, const float *in, const float *targ) {
     float v = 0;
     check(mlggd_cv_sqerr(h_, n, in, targ, &v), "mlggd_cv_sqerr");

@@ -13,6 +13,10 @@ class BP_GPU {
            int dropoutflag, float visible_omit, float hid_omit);
     ~BP_GPU();
     void train(int n_frames, float *in, const float *targ);
+    // One SGD step on n_frames = bunchsize rows (BP_GPU.h:53, BP_GPU.cu:308-440).  The reference's member is public
+    // but takes pointers into its private device workspace (train passes dev.in + offset, BP_GPU.cu:170-184), so no
+    // outside caller can use it there; here it takes HOST rows like train() does: upload + one step + wait.
+    void train_bunch_single(int n_frames, float *in, const float *targ);
     float CrossValid(int n_frames, const float *in, const float *targ);
     float CrossValiddB(int n_frames, const float *in, const float *targ);
     float CrossValid2(int n_frames, const float *in, const float *targ);

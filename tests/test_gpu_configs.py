@@ -216,16 +216,19 @@ def test_config1_executable_on_a_tiny_pfile_at_the_real_shape(pkg, pyoracle, tmp
     ora.close()
 
 
-@pytest.mark.parametrize("ml,beta", [(1, 1.2), (1, 0.9), (0, 2.0)])
+@pytest.mark.parametrize("ml,beta", [(1, 1.2), (1, 1.0), (1, 0.9), (0, 2.0)])
 def test_epoch_horizon_one_full_chunk_of_800_steps(pkg, pyoracle, synth, ml, beta):
     """north_star: "per-epoch ML-GGD loss matching the reference to 1e-4 rel".  One traincache-sized chunk of
     102,400 samples = 800 steps of 128 frames at 2827-2048^3-257 (TC/BP_GPU.cu:170-184), then the three numbers
     the reference logs after an epoch (TC/BPtrain.cc:112-139: CV squared error, |error|/D, GGD log-likelihood)
     on a held-out chunk, and alpha, the per-dimension GGD scale the last step leaves behind (BP_GPU.cu:417-420).
 
-    beta >= 1 (MMSE, ML beta 1.2): CV numbers within 1e-4 relative -- the north_star figure -- (measured r02:
+    beta > 1 (MMSE, ML beta 1.2): CV numbers within 1e-4 relative -- the north_star figure -- (measured r02:
     1e-6 .. 4e-6), alpha within 5e-4 of its maximum (8.6e-5), weights within 2e-3 of max|W| (1.5e-4 .. 8.4e-4:
     800 steps of two fp32 trajectories with different summation orders).
+
+    beta = 1 (the shipped objective): CV numbers within 1e-4 relative as well; alpha and the weights bounded by the
+    oracle's own order twins as for beta = 0.9 below (the sign gradient jumps where an error crosses zero).
 
     beta = 0.9 -- PARITY UNPINNED, and not reachable at 1e-4 by ANY implementation that is not bit-identical to the
     reference build: the loss itself is ill-conditioned (the gradient sgn(e)|e|^(beta-1) jumps where an error
@@ -271,7 +274,7 @@ def test_epoch_horizon_one_full_chunk_of_800_steps(pkg, pyoracle, synth, ml, bet
     print("epoch horizon ml=%d beta=%.1f: HIP vs oracle: sqerr %.1e abserr %.1e loglik %.1e | alpha relrms %.1e relmax %.1e | "
           "weights relrms %.1e relmax %.1e" % (ml, beta, d_hip["sq"], d_hip["ab"], d_hip["ll"], d_hip["alpha"],
                                                d_hip["alpha_max"], d_hip["w"], d_hip["w_max"]))
-    if beta >= 1.0:
+    if beta > 1.0:
         assert d_hip["sq"] <= 1e-4 and d_hip["ab"] <= 1e-4 and d_hip["ll"] <= 1e-4
         assert d_hip["alpha_max"] < 5e-4 and d_hip["w_max"] < 2e-3
     else:
@@ -281,13 +284,17 @@ def test_epoch_horizon_one_full_chunk_of_800_steps(pkg, pyoracle, synth, ml, bet
         for sp, t in zip((4, 7), twins):
             print("   oracle order twin (split %d) vs oracle: sqerr %.1e abserr %.1e loglik %.1e | alpha relrms %.1e relmax %.1e | "
                   "weights relrms %.1e relmax %.1e" % (sp, t["sq"], t["ab"], t["ll"], t["alpha"], t["alpha_max"], t["w"], t["w_max"]))
-        # Measured r03: HIP vs oracle 8.7e-5 / 5.2e-5 / 9.4e-5 (all three inside the north_star's 1e-4 this time; r02's
-        # build: 1.05e-4 on the first), twins 3.4e-5 / 2.9e-5 / 3.8e-5 and 3.0e-5 / 3.0e-6 / 1.6e-5 -- the twins differ
-        # from each other by 10x in one number, so the CV numbers pass at 1e-4 OR inside K_TWIN x the yardstick.  alpha
-        # (relrms 1.3e-3 vs 1.4e-3 / 1.3e-3) and the weights (6.6e-3 vs 6.9e-3 / 6.7e-3) sit exactly ON the twins'
+        # beta = 0.9, measured r03: HIP vs oracle 8.7e-5 / 5.2e-5 / 9.4e-5 (all three inside the north_star's 1e-4 this
+        # time; r02's build: 1.05e-4 on the first), twins 3.4e-5 / 2.9e-5 / 3.8e-5 and 3.0e-5 / 3.0e-6 / 1.6e-5 -- the twins
+        # differ from each other by 10x in one number, so the CV numbers pass at 1e-4 OR inside K_TWIN x the yardstick.
+        # alpha (relrms 1.3e-3 vs 1.4e-3 / 1.3e-3) and the weights (6.6e-3 vs 6.9e-3 / 6.7e-3) sit exactly ON the twins'
         # distance: the divergence is the trajectory's own, saturated at the same level whatever perturbs it.
+        # beta = 1 (the SHIPPED objective, TC/finetune.pl:25-26; r04): the gradient sgn(e) / sum|e| is bounded but still
+        # jumps by 2 / sum|e| where an error crosses zero, so alpha and the weights drift the same way (HIP vs oracle
+        # alpha relrms 5.4e-4, weights 2.2e-3: bounded by the twins like beta = 0.9) -- while the three numbers the
+        # reference LOGS stay at 2.7e-5 / 2.7e-5 / 1.9e-5 and are held to the north_star's plain 1e-4.
         for k in ("sq", "ab", "ll"):
-            assert d_hip[k] <= max(1e-4, K_TWIN * yard[k]), (k, d_hip[k], yard[k])
+            assert d_hip[k] <= (1e-4 if beta == 1.0 else max(1e-4, K_TWIN * yard[k])), (k, d_hip[k], yard[k])
         for k in ("alpha", "w"):
             assert d_hip[k] <= K_TWIN * yard[k], (k, d_hip[k], yard[k])
         assert d_hip["sq"] <= 1e-3 and d_hip["ab"] <= 1e-3 and d_hip["ll"] <= 1e-3  # and never an order of magnitude worse

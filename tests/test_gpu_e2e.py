@@ -20,7 +20,7 @@ def relmax(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
 
 
-@pytest.mark.parametrize("ml,beta", [(0, 2.0), (0, 1.0), (1, 2.0), (1, 1.2), (1, 0.9)])
+@pytest.mark.parametrize("ml,beta", [(0, 2.0), (0, 1.0), (1, 2.0), (1, 1.2), (1, 1.0), (1, 0.9)])
 def test_tiny_goldens(pkg, synth, ml, beta):
     g = np.load(os.path.join(GOLD, "tiny_net.npz"))
     ls, B = [int(x) for x in g["layersizes"]], int(g["bunch"])
@@ -44,7 +44,7 @@ def test_tiny_goldens(pkg, synth, ml, beta):
     eng.close()
 
 
-@pytest.mark.parametrize("ml,beta", [(0, 2.0), (1, 1.2)])
+@pytest.mark.parametrize("ml,beta", [(0, 2.0), (1, 1.2), (1, 1.0)])
 def test_baseline_goldens(pkg, synth, ml, beta):
     g = np.load(os.path.join(GOLD, "baseline_net.npz"))
     ls, B = synth.baseline_layersizes(), int(g["bunch"])

@@ -62,6 +62,18 @@ def test_device_powf_and_expf_in_ulps(pkg, synth):
                        int(d_dh.max()), float((d_dh > 0).mean())))
         assert d_dev.max() <= 2, (y, d_dev.max())        # ocml powf: measured 1 ulp max, 11-23 % of the values 1 ulp off
         assert d_host.max() <= 1, (y, d_host.max())      # glibc powf: measured correctly rounded in 99.9 % of the cases
+    # y = 1 and y = 0 (the shipped objective, MLflag = 1 shapefactor = 1, TC/finetune.pl:25-26, meets exactly these:
+    # |e|^1, v2^(1/1), alpha^1, |e|^0): the correctly rounded results are x and 1.  glibc returns them; what ocml's
+    # powf returns is REPORTED here, not relied on -- the kernels never call powf for these exponents (pow_or_self,
+    # kernels.hip.h), so the beta = 1 chain is bit-identical to the oracle's (test below).
+    for y, want in ((1.0, x), (0.0, np.ones_like(x))):
+        dev = eng.debug_math("powf", x, np.float32(y))
+        d = ulp_dist(dev, want)
+        host = glibc_powf(x[:20000], np.float32(y))
+        assert np.array_equal(host, want[:20000])        # glibc: exact
+        print("powf(x, %.1f): device vs the exact result max %d ulp (%.1f %% differ); glibc exact"
+              % (y, d.max(), 100 * (d > 0).mean()))
+        assert d.max() <= 2
     for r in report:
         print("powf(x, %+.4f): device vs exact max %d ulp (%.1f %% differ) | glibc vs exact max %d ulp (%.1f %%) | "
               "device vs glibc max %d ulp (%.1f %% differ)" % (r[0], r[1], 100 * r[2], r[3], 100 * r[4], r[5], 100 * r[6]))
@@ -79,7 +91,7 @@ def test_device_powf_and_expf_in_ulps(pkg, synth):
     eng.close()
 
 
-@pytest.mark.parametrize("beta", [0.9, 1.2, 2.0])
+@pytest.mark.parametrize("beta", [0.9, 1.0, 1.2, 2.0])
 @pytest.mark.parametrize("fused", [True, False])
 def test_loss_chain_on_an_exactly_representable_output_layer(pkg, pyoracle, beta, fused, monkeypatch):
     """fused: k_loss_ml (single device, one launch); not fused: k_loss_err + k_loss_grad (the data-parallel pair)."""
@@ -108,10 +120,24 @@ def test_loss_chain_on_an_exactly_representable_output_layer(pkg, pyoracle, beta
           % (beta, "k_loss_ml" if fused else "k_loss_err+k_loss_grad", dg.max(), 100 * (dg > 0).mean(), dg.mean(), da.max(),
              100 * (da > 0).mean()))
     # Measured r03 (MI355X, ROCm 7.2): dEdX_L max 5-6 ulp, mean 0.7-1.0 ulp, about half of the elements differ at all;
-    # alpha max 1 (beta 2) .. 3 ulp.  Every element's gradient is sgn(e) |e|^(beta-1) beta / alpha^beta / n: three powf
-    # results (each within 1 ulp of exact on the device, correctly rounded in 99.9 % of the cases by glibc) and, through
-    # alpha, the sum of 128 more.  Note powf(x, 2) is NOT x*x on the device (1 ulp off in 23 % of the cases), so beta = 2
-    # with MLflag = 1 is no exception; MLflag = 0 with beta = 2 takes powf(x, 1) = x and is bit-exact.
-    assert da.max() <= 4 and dg.max() <= 12 and dg.mean() <= 1.5
+    # alpha max 1 (beta 2) .. 3 ulp.  Note powf(x, 2) is NOT x*x on the device (1 ulp off in 23 % of the cases), so
+    # beta = 2 with MLflag = 1 is no exception; MLflag = 0 with beta = 2 takes pow(x, 1) = x and is bit-exact.
+    if beta == 1.0:
+        # the shipped objective: no libm call left in the chain (pow_or_self), kernSumcol's order kept -> same bits
+        assert dg.max() == 0 and da.max() == 0
+    else:
+        # The bound, derived rather than chosen.  D = 1 ulp is the measured device-vs-glibc distance of ONE powf call
+        # (first test of this file).  g = P * beta / q * inv_n with P = powf(|e|, beta-1), q = powf(alpha, beta):
+        #   P: D;   q: alpha is da ulp off (measured in THIS run, below), powf scales a relative input error by its
+        #   exponent, and a relative error is worth up to 2x as many ulps on the other side of a binade boundary
+        #   -> 2 * beta * da + D;   the mul / div / mul that follow are IEEE on both sides but act on perturbed inputs:
+        #   +1 ulp each for the two whose inputs differ.
+        # alpha itself: v2 is a sum of 128 positive terms each within D -> within 2 D ulp; powf(v2, 1/beta) -> 2/beta * 2D + D.
+        D = 1
+        bound_a = int(np.ceil(4.0 * D / beta + D))
+        bound_g = int(np.ceil(D + 2.0 * beta * int(da.max()) + D + 2))
+        assert da.max() <= bound_a, (int(da.max()), bound_a)
+        assert dg.max() <= bound_g, (int(dg.max()), bound_g)
+        assert dg.mean() <= 1.5
     eng.close()
     ora.close()

@@ -10,7 +10,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-CASES = [(0, 2.0), (0, 1.0), (1, 2.0), (1, 1.2), (1, 0.9)]
+CASES = [(0, 2.0), (0, 1.0), (1, 2.0), (1, 1.2), (1, 1.0), (1, 0.9)]
 
 
 def relmax(a, b):
@@ -157,7 +157,7 @@ def test_forward_and_dx_loop_variants(pkg, pyoracle, synth, monkeypatch):
     ora.close()
 
 
-@pytest.mark.parametrize("ml,beta", [(0, 2.0), (1, 1.2)])
+@pytest.mark.parametrize("ml,beta", [(0, 2.0), (1, 1.2), (1, 1.0)])
 def test_baseline_net_two_steps(pkg, pyoracle, synth, ml, beta):
     """BASELINE.json configs 2/3: 2827-2048x3-257, 128-frame minibatch."""
     ls, B = synth.baseline_layersizes(), 128

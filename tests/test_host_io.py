@@ -12,6 +12,7 @@ import sys
 import numpy as np
 import pytest
 
+import finetune_recorder
 import hostlib
 
 REF = "/root/reference/tools_pfile"
@@ -294,44 +295,27 @@ def test_rendezvous_never_accepts_a_stale_id_file(tmp_path):
         hostlib.rendezvous(path, 2, 1, None, timeout=0.2)
 
 
-FINETUNE = "/root/reference/Train_code_ML_GGD/finetune.pl"
-
-
-@pytest.mark.skipif(not (os.path.exists(FINETUNE) and shutil.which("perl")), reason="reference tree / perl not present")
+@pytest.mark.skipif(not finetune_recorder.available(), reason="reference tree / perl not present")
 def test_reference_finetune_pl_argv_through_the_parser(tmp_path):
     """the reference's epoch driver `finetune.pl` must run unmodified against the new binary
     except `$exe`.  The script itself is run here by perl (in-container only; nothing of it is committed or shipped:
-    a temporary copy gets its `$exe` line pointed at a recorder), and every argv its three system() call sites emit
-    (finetune.pl:50-76 epoch 1, :89-115 epochs 2-10, :127-153 epochs 11-50) goes through Interface::Initial; each
-    key must land where the reference's parser puts it (Interface.cc:150-315): strings verbatim, ints by atoi,
-    floats by atof -> float; `numlayers=` is not a key of that parser (the count comes from layersizes=)."""
-    top = tmp_path / "ref"
-    tc = top / "Train_code_ML_GGD"
-    (tc / "pretraining_weights").mkdir(parents=True)
-    os.symlink("/root/reference/tools_pfile", top / "tools_pfile")  # $ROOT_DIR/tools_pfile = the reference's sample data
-    script = open(FINETUNE).read()
-    rec = tc / "recorder.py"
-    log = tc / "argv.jsonl"
-    rec.write_text("#!%s\nimport json, os, sys\n"
-                   "open(%r, 'a').write(json.dumps(sys.argv[1:]) + '\\n')\n"
-                   "kv = dict(a.split('=', 1) for a in sys.argv[1:])\n"
-                   "# the next epoch starts from this epoch's output: stand in for it with the initial weights\n"
-                   "os.symlink(os.path.realpath(kv['initwts_file']), kv['outwts_file'])\n" % (sys.executable, str(log)))
-    rec.chmod(0o755)
-    patched, n = re.subn(r'(my \$exe\s*=\s*)"[^"]*";', lambda m: m.group(1) + '"./recorder.py";', script)
-    assert n == 1  # the ONE line a user edits
-    (tc / "finetune.pl").write_text(patched)
-    # the init file finetune.pl:47 names is not shipped by the reference: gen_rand_net makes it (SURVEY 8f3)
-    ls = [1799, 2048, 2048, 2048, 257]
+    a temporary copy gets its `$exe` line pointed at a recorder, tests/finetune_recorder.py), and every argv its three
+    system() call sites emit (finetune.pl:50-76 epoch 1, :89-115 epochs 2-10, :127-153 epochs 11-50) goes through
+    Interface::Initial; each key must land where the reference's parser puts it (Interface.cc:150-315): strings
+    verbatim, ints by atoi, floats by atof -> float; `numlayers=` is not a key of that parser (the count comes from
+    layersizes=).  The recorded lists are also what tests/golden/finetune_argv.json holds (the GPU test
+    tests/test_gpu_finetune.py drives BPtrain_Sigmoid with them): the fixture must equal today's recording."""
+    ls = finetune_recorder.LAYERS
     hostlib.lib()
-    subprocess.check_call([os.path.join(hostlib.HOST, "gen_rand_net"), "5", *map(str, ls), str(tc / "pretraining_weights"),
-                           str(tc / "pretraining_weights" / "Rand_1799_3hid2048_257_beta2.wts"), "1", "2", "5"],
-                          stdout=subprocess.DEVNULL)
-    r = subprocess.run(["perl", "finetune.pl"], cwd=tc, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stderr
-    argvs = [json.loads(x) for x in open(log)]
+
+    def make_init(path):   # the init file finetune.pl:47 names is not shipped by the reference: gen_rand_net makes it (SURVEY 8f3)
+        subprocess.check_call([os.path.join(hostlib.HOST, "gen_rand_net"), "5", *map(str, ls), os.path.dirname(path), path,
+                               "1", "2", "5"], stdout=subprocess.DEVNULL)
+
+    argvs, tc = finetune_recorder.record(tmp_path, make_init)
     assert len(argvs) == 50  # one process per epoch
     assert all(len(a) == 25 and a[1] == "numlayers=5" for a in argvs)
+    assert json.load(open(finetune_recorder.FIXTURE))["argv"] == argvs
 
     seed, lrate = 27870775, 0.1
     for epoch in (1, 2, 10, 11, 12, 50):

@@ -9,7 +9,7 @@ import pytest
 from ref64 import Ref64
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = [(0, 2.0), (0, 1.0), (1, 2.0), (1, 1.2), (1, 0.9)]
+CASES = [(0, 2.0), (0, 1.0), (1, 2.0), (1, 1.2), (1, 1.0), (1, 0.9)]
 HP = (0.1, 0.9, 1e-5)
 
 
@@ -65,14 +65,15 @@ def test_oracle_matches_tiny_goldens_bit_exact(pyoracle, synth, ml, beta):
     assert o.cv_abserr(inp, targ) == np.float32(cv[1])
 
 
-def test_oracle_matches_baseline_goldens(pyoracle, synth):
+@pytest.mark.parametrize("beta", [1.2, 1.0])
+def test_oracle_matches_baseline_goldens(pyoracle, synth, beta):
     g = np.load(os.path.join(GOLD, "baseline_net.npz"))
     ls, B = synth.baseline_layersizes(), int(g["bunch"])
     ws, bs = synth.make_weights(ls)
     inp, targ = synth.make_frames(2 * B, 257, 11)
-    o = pyoracle.OracleNet(ls, B, *HP, 1.2, 1, ws, bs)
+    o = pyoracle.OracleNet(ls, B, *HP, beta, 1, ws, bs)
     assert o.train(inp, targ) == 2
-    key = "ml1_b1.2"
+    key = "ml1_b%s" % beta
     w, b = o.get_weights()
     for l in range(4):
         idx = g["%s_idx%d" % (key, l + 1)]
@@ -148,7 +149,7 @@ def test_zero_error_gradient_is_zero(pyoracle, synth):
 
 
 @pytest.mark.parametrize("shape", ["tiny", "baseline"])
-@pytest.mark.parametrize("ml,beta", [(0, 2.0), (1, 1.2), (1, 0.9)])
+@pytest.mark.parametrize("ml,beta", [(0, 2.0), (1, 1.2), (1, 1.0), (1, 0.9)])
 def test_fma_contraction_variant_is_inside_the_gpu_tolerances(pyoracle, synth, ml, beta, shape):
     """Ambiguity (viii), oracle/mlggd_oracle.c: the reference is built with nvcc's default --fmad=true
     (TC/Makefile:30-33), so its elementwise kernels (kernUpdatedelta, TC/DevFunc.cu:502) and cuBLAS contract

@@ -25,7 +25,7 @@ for case in range(N):
     nh = int(rng.integers(0, 5))
     ls = [dim * ctx] + [int(rng.integers(1, 300)) for _ in range(nh)] + [dim]
     B = int(rng.choice([1, 7, 32, 50, 64, 100, 128, 192, 256, 300]))
-    ml, beta = [(0, 2.0), (0, 1.0), (1, 2.0), (1, 1.2), (1, 0.9)][int(rng.integers(0, 5))]
+    ml, beta = [(0, 2.0), (0, 1.0), (1, 2.0), (1, 1.2), (1, 1.0), (1, 0.9)][int(rng.integers(0, 6))]
     if ml == 1 and B < 7:
         ml, beta = 0, 2.0  # the ML gradient is ~1/|e| with a one-frame minibatch: ill-conditioned, not a parity case
     steps = int(rng.integers(1, 4))
@@ -41,7 +41,7 @@ for case in range(N):
     nfr = steps * world * B + ctx + 40
     feat = rng.standard_normal((nfr, dim), dtype=np.float32)
     targ_fr = (0.5 * feat + 0.5 * rng.standard_normal((nfr, dim), dtype=np.float32)).astype(np.float32)
-    first = rng.permutation(nfr - ctx + 1)[:steps * world * B + int(rng.integers(0, 5))].astype(np.int32)
+    first = rng.permutation(nfr - ctx + 1)[:steps * world * B + int(rng.integers(0, 6))].astype(np.int32)
     toff = int(rng.integers(0, ctx))
     steps = len(first) // (world * B)  # a small B turns the ragged tail into extra full bunches
     idx = first[:, None] + np.arange(ctx)[None, :]
