@@ -185,8 +185,7 @@ int main(int argc, char *argv[]) {
         std::vector<float> loc_in, loc_targ;
         for (unsigned i = 0; i < io->total_chunks; i++) {
             progress("waiting for a chunk");
-            slot.wait(true);
-            if (io->cur_chunk_samples < 0) break;
+            if (!slot.wait(true)) break;  // the reader failed: its message is raised after the join below
             progress("training a chunk");
             io->logf("Starting chunk %d of %d containing %d samples.\n", i + 1, io->total_chunks, io->cur_chunk_samples);
             if (io->fp_log) fflush(io->fp_log);

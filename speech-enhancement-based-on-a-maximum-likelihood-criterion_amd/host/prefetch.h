@@ -14,19 +14,32 @@
 
 namespace mlggd_host {
 
-// Two-slot hand-off between the fetch thread and the trainer.
+// Two-slot hand-off between the fetch thread and the trainer.  `failed` is the reader's error hand-off: it is part of
+// the wait predicate and nothing clears it, so a reader that dies while the trainer is still busy with the previous
+// chunk (slot full, a later set(false) by the trainer) cannot be missed -- the trainer's next wait(true) returns
+// false instead of blocking for ever on a thread that is gone.
 struct Slot {
     std::mutex m;
     std::condition_variable cv;
     bool full = false;
-    void wait(bool want) {
+    bool failed = false;
+    // false: the reader has failed; nothing further will be handed over
+    bool wait(bool want) {
         std::unique_lock<std::mutex> lk(m);
-        cv.wait(lk, [&] { return full == want; });
+        cv.wait(lk, [&] { return failed || full == want; });
+        return !failed;
     }
     void set(bool v) {
         {
             std::lock_guard<std::mutex> lk(m);
             full = v;
+        }
+        cv.notify_all();
+    }
+    void fail() {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            failed = true;
         }
         cv.notify_all();
     }
@@ -61,10 +74,11 @@ inline void fetch_loop(Interface *io, Slot *slot, std::string *error, bool frame
             slot->set(true);
         }
     } catch (const std::exception &e) {
+        // the message is complete before fail() publishes it (the slot's mutex orders the two); cur_chunk_samples is
+        // NOT touched here: the trainer may be reading it for the chunk it still holds
         *error = e.what();
         if (error_suffix && !error_suffix->empty()) *error += ": " + *error_suffix;
-        io->cur_chunk_samples = -1;
-        slot->set(true);
+        slot->fail();
     }
 }
 

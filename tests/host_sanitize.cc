@@ -8,12 +8,15 @@
 // reader thread ahead of a "trainer" that reads every byte of every chunk -- in both chunk forms (frame stream /
 // expanded), then the CV chunks and the weight file.
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
 #include <vector>
+
+#include <unistd.h>
 
 #include "prefetch.h"
 #include "trainer_io.h"
@@ -40,12 +43,15 @@ static void write_wts(const std::string &path, const std::vector<int> &ls) {  //
     fclose(f);
 }
 
-static double epoch(Interface *io, bool frames) {
+// slow_first_chunk_ms > 0: the consumer dwells on chunk 0, so a reader that fails on chunk 1 does so while the slot
+// is still full (that error used to be lost and the trainer blocked for ever).  expect_error: the reader's
+// message is returned through *reader_error instead of ending the process.
+static double epoch(Interface *io, bool frames, int slow_first_chunk_ms = 0, std::string *reader_error = nullptr) {
     WorkPara *p = io->para;
     io->get_chunk_info(p->train_sent_range);
     io->chunk_index.resize(io->total_chunks);
     for (unsigned i = 0; i < io->total_chunks; i++) io->chunk_index[i] = (int)i;
-    io->GetRandIndex(io->chunk_index.data(), (int)io->total_chunks);
+    if (slow_first_chunk_ms == 0) io->GetRandIndex(io->chunk_index.data(), (int)io->total_chunks);  // else file order: chunk 0 is readable
     Slot slot;
     std::string err;
     std::atomic<bool> stop{false};
@@ -53,8 +59,8 @@ static double epoch(Interface *io, bool frames) {
     const int K0 = p->layersizes[0], D = p->layersizes[io->numlayers - 1];
     double sum = 0;
     for (unsigned i = 0; i < io->total_chunks; i++) {
-        slot.wait(true);
-        if (io->cur_chunk_samples < 0) break;
+        if (!slot.wait(true)) break;
+        if (slow_first_chunk_ms > 0 && i == 0) std::this_thread::sleep_for(std::chrono::milliseconds(slow_first_chunk_ms));
         const int n = io->cur_chunk_samples;
         if (frames) {  // every frame, every first-frame index, and the window each index addresses
             const int nf = p->chunk_frames[1];
@@ -72,7 +78,8 @@ static double epoch(Interface *io, bool frames) {
         slot.set(false);
     }
     fetch.join();
-    if (!err.empty()) { fprintf(stderr, "reader: %s\n", err.c_str()); exit(2); }
+    if (reader_error) *reader_error = err;
+    else if (!err.empty()) { fprintf(stderr, "reader: %s\n", err.c_str()); exit(2); }
     return sum;
 }
 
@@ -136,6 +143,41 @@ int main(int argc, char **argv) {
             return 2;
         }
         delete io;
+    }
+    // A pfile cut off in the middle of its data (a crashed feacat, a full disk): the header still promises every
+    // frame, so the planner lays out all chunks and the READER hits the end of the file on a later chunk -- while
+    // the consumer is still busy with chunk 0.  The epoch must end with the reader's message, not hang.
+    for (int form = 0; form < 2; form++) {
+        FILE *f = fopen((d + "/n.pfile").c_str(), "rb");
+        if (!f) return 2;
+        std::vector<char> all;
+        char buf[65536];
+        size_t got;
+        while ((got = fread(buf, 1, sizeof(buf), f)) > 0) all.insert(all.end(), buf, buf + got);
+        fclose(f);
+        f = fopen((d + "/cut.pfile").c_str(), "wb");
+        if (!f) return 2;
+        fwrite(all.data(), 1, all.size(), f);
+        fclose(f);
+        std::vector<std::string> copy = a;
+        for (auto &s : copy)
+            if (s.rfind("fea_file=", 0) == 0) s = "fea_file=" + d + "/cut.pfile";
+        std::vector<char *> av;
+        for (auto &s : copy) av.push_back(&s[0]);
+        Interface *io = new Interface;
+        std::string reader_error;
+        try {
+            io->Initial((int)av.size(), av.data(), /*open_output=*/false);
+            io->get_pfile_info();  // header and sentence table read while the file is whole
+            const size_t row = 8 + 4 * (size_t)dim;
+            if (truncate((d + "/cut.pfile").c_str(), (off_t)(32768 + row * 150)) != 0) return 2;  // 150 of the 471 frames stay
+            epoch(io, form == 0, /*slow_first_chunk_ms=*/200, &reader_error);
+        } catch (const std::exception &e) {  // a reader that notices the truncation up front is fine too
+            reader_error = e.what();
+        }
+        delete io;
+        if (reader_error.empty()) { fprintf(stderr, "host_sanitize: the truncated pfile went unnoticed (form %d)\n", form); return 2; }
+        printf("truncated pfile, form %d: reader error handed over: %s\n", form, reader_error.c_str());
     }
     printf("host_sanitize OK: frame-stream checksum %.6f, expanded checksum %.6f\n", sums[0], sums[1]);
     return 0;

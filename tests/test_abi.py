@@ -84,3 +84,55 @@ def test_create_rejects_bad_arguments_before_touching_a_device(pkg):
     assert rc != 0 and "too large" in msg
     rc, msg = create([100, 0, 10], 8)
     assert rc != 0 and "layersizes[1]" in msg
+
+
+REF_TC = "/root/reference/Train_code_ML_GGD"
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF_TC, "BPtrain.cc")), reason="reference tree not present")
+def test_reference_main_builds_and_links_against_the_bp_gpu_shim(pkg, tmp_path):
+    """INTEGRATION.md section 2 as a test: the reference's own host half -- TC/BPtrain.cc (main, threadFetch) and
+    TC/Interface.cc, unmodified -- compiles and links against `class BP_GPU` of host/bp_gpu.h + libmlggd.so, with the
+    one change a maintainer makes: BP_GPU.h (which hard-wires /usr/local/cuda-9.0 headers, TC/BP_GPU.h:3-5) becomes a
+    one-line forward to host/bp_gpu.h.  Call sites covered by the link: the constructor (BPtrain.cc:77-78), train
+    (:98), returnWeights (:108), CrossValid / CrossValiddB / CrossValid2 (:124-128), the destructor (:143).
+    In-container only; everything lives in tmp_path (the sources are symlinked there so that `#include "BP_GPU.h"`
+    resolves to the forwarding header, not to the file next to them); nothing of the reference is committed.  The
+    binary is then RUN on the reference's sample pfiles with the reference's shipped argument list (finetune.pl's
+    epoch-1 form): without a GPU it must get as far as the engine's constructor and stop with the engine's own
+    message; with one it trains the epoch."""
+    import json
+    import subprocess
+    import hostlib
+    pkg.build()
+    hostlib.lib()                                   # builds gen_rand_net as well
+    host = os.path.join(os.path.dirname(pkg.LIB_PATH), "..", "host")
+    csrc = os.path.dirname(pkg.LIB_PATH)
+    for f in ("BPtrain.cc", "Interface.cc", "Interface.h"):
+        os.symlink(os.path.join(REF_TC, f), tmp_path / f)
+    (tmp_path / "BP_GPU.h").write_text('#include "%s"\n' % os.path.abspath(os.path.join(host, "bp_gpu.h")))
+    exe = tmp_path / "BPtrain_ref"
+    r = subprocess.run(["g++", "-O1", "-w", "-o", str(exe), str(tmp_path / "BPtrain.cc"), str(tmp_path / "Interface.cc"),
+                        os.path.join(host, "bp_gpu.cc"), "-L" + csrc, "-lmlggd", "-lpthread", "-Wl,-rpath," + csrc,
+                        "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    # the public members of the reference class the shim must carry (TC/BP_GPU.h:48-59), train_bunch_single included
+    hdr = open(os.path.join(host, "bp_gpu.h")).read()
+    for member in ("train(", "train_bunch_single(", "CrossValid(", "CrossValiddB(", "CrossValid2(", "cv_bunch_single(",
+                   "returnWeights(", "Gamma("):
+        assert member in hdr, member
+    ls = [1799, 2048, 2048, 2048, 257]
+    subprocess.check_call([os.path.join(host, "gen_rand_net"), "5", *map(str, ls), str(tmp_path), str(tmp_path / "init.wts"),
+                           "1", "2", "5"], stdout=subprocess.DEVNULL)
+    argv = json.load(open(os.path.join(ROOT, "tests", "golden", "finetune_argv.json")))["argv"][0]
+    sub = {"initwts_file": tmp_path / "init.wts", "outwts_file": tmp_path / "mlp.1.wts", "log_file": tmp_path / "mlp.1.log",
+           "norm_file": "/root/reference/tools_pfile/train_noisy.norm", "fea_file": "/root/reference/tools_pfile/train_noisy.pfile",
+           "targ_file": "/root/reference/tools_pfile/train_clean.pfile"}
+    argv = ["%s=%s" % (a.split("=", 1)[0], sub.get(a.split("=", 1)[0], a.split("=", 1)[1])) for a in argv]
+    r = subprocess.run([str(exe)] + argv, capture_output=True, text=True, timeout=300)
+    import torch
+    if torch.cuda.is_available():
+        assert "all finish" in r.stdout and os.path.getsize(tmp_path / "mlp.1.wts") > 4 * 1799 * 2048
+    else:
+        assert "mlggd_device_count failed" in r.stdout + r.stderr     # reached BP_GPU::BP_GPU through the shim
+        assert "Get pfile info" not in r.stdout                        # ... and stopped there (BPtrain.cc:77 comes first)
