@@ -58,6 +58,8 @@ struct RcclApi {
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclAllReduce) AllReduce_ = nullptr;
     decltype(&ncclAllGather) AllGather_ = nullptr;
+    decltype(&ncclReduceScatter) ReduceScatter_ = nullptr;
+    decltype(&ncclCommSplit) CommSplit = nullptr;        // optional: MLGGD_DP_STAT_COMM
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclGetErrorString) GetErrorString_ = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
@@ -71,6 +73,10 @@ struct RcclApi {
     }
     int AllGather(const void *s, void *r, size_t n, int, RcclComm c, hipStream_t st) const {
         return (int)AllGather_(s, r, n, ncclFloat32, c, st);
+    }
+    // r receives this rank's block of n floats of the sum over the ranks of the world*n floats at s
+    int ReduceScatter(const void *s, void *r, size_t n, RcclComm c, hipStream_t st) const {
+        return (int)ReduceScatter_(s, r, n, ncclFloat32, ncclSum, c, st);
     }
     const char *GetErrorString(int rc) const { return GetErrorString_ ? GetErrorString_((ncclResult_t)rc) : "rccl error"; }
 };
@@ -88,13 +94,15 @@ static int rccl_load() {
     g_rccl.CommInitRank = (decltype(&ncclCommInitRank))dlsym(lib, "ncclCommInitRank");
     g_rccl.AllReduce_ = (decltype(&ncclAllReduce))dlsym(lib, "ncclAllReduce");
     g_rccl.AllGather_ = (decltype(&ncclAllGather))dlsym(lib, "ncclAllGather");
+    g_rccl.ReduceScatter_ = (decltype(&ncclReduceScatter))dlsym(lib, "ncclReduceScatter");
+    g_rccl.CommSplit = (decltype(&ncclCommSplit))dlsym(lib, "ncclCommSplit");
     g_rccl.CommDestroy = (decltype(&ncclCommDestroy))dlsym(lib, "ncclCommDestroy");
     g_rccl.GetErrorString_ = (decltype(&ncclGetErrorString))dlsym(lib, "ncclGetErrorString");
     g_rccl.GroupStart = (decltype(&ncclGroupStart))dlsym(lib, "ncclGroupStart");
     g_rccl.GroupEnd = (decltype(&ncclGroupEnd))dlsym(lib, "ncclGroupEnd");
     g_rccl.CommCount = (decltype(&ncclCommCount))dlsym(lib, "ncclCommCount");
     g_rccl.CommUserRank = (decltype(&ncclCommUserRank))dlsym(lib, "ncclCommUserRank");
-    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce_ || !g_rccl.AllGather_ || !g_rccl.CommDestroy ||
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce_ || !g_rccl.AllGather_ || !g_rccl.ReduceScatter_ || !g_rccl.CommDestroy ||
         !g_rccl.GroupStart || !g_rccl.GroupEnd)
         return fail(MLGGD_ERR_COMM, "librccl is missing required symbols");
     g_rccl.lib = lib;
@@ -231,6 +239,15 @@ struct mlggd_engine {
     int dp_mainline = 1;
     bool comm_after_dw = false;  // the communication stream has already waited on an event recorded after the last dW launch
     RcclComm comm = nullptr;
+    // MLGGD_DP_STAT_COMM=1: the 257-float all-reduce of the ML statistic gets a communicator of its own (ncclCommSplit
+    // of `comm`), so that it does not queue behind the factor / weight collectives of `comm` that are still in flight
+    // (collectives of ONE communicator execute in issue order whatever stream they are on).  Off by default: untested
+    // between two GPUs.
+    RcclComm stat_comm = nullptr;
+    // all-reduce exchange (dp_mode 0): 1 = reduce-scatter of G_l over weight-row blocks, update of this rank's block
+    // only, all-gather of the W blocks (same link bytes as the all-reduce, 1/world of the update traffic);
+    // 0 (MLGGD_DP_AR_SHARD=0) = all-reduce of G_l and the full update on every rank (rounds 1-3, A/B)
+    int ar_shard = 1;
     hipEvent_t ev_grad[MLGGD_MAXLAYER] = {0}, ev_red[MLGGD_MAXLAYER] = {0}, ev_bias = nullptr, ev_bias_red = nullptr;
 
     // timing
@@ -519,6 +536,8 @@ enum { GATHER_INPUT = 1, GATHER_HIDDEN = 2, GATHER_HIDDEN_EACH = 4 };  // data-p
 
 static int run_forward(mlggd_engine *e, const Bunch &bn, int frames, bool training, bool prestaged = false,
                        int gather_flags = 0) {
+    e->stop_ev_next = nullptr;  // an event armed by a launch sequence that bailed out early must not ride on an unrelated launch
+    e->stop_ev_attached = false;
     if (prestaged) {
         e->in_bunch = in_bunch_other(e);
     } else {
@@ -849,9 +868,14 @@ static int gather_alloc(mlggd_engine *e) {
     // both forms in every multi-GPU run (dp_arms.gather_other_granularity).
     if (const char *v = getenv("MLGGD_DP_FINE")) e->dp_fine = atoi(v);
     else e->dp_fine = 0;
+    return MLGGD_OK;
+}
+// Launch-order knobs of every data-parallel mode (A/B switches; the defaults rest on a 1-rank rehearsal and on
+// emulated worlds -- nothing has run between two GPUs yet).
+static void dp_knobs(mlggd_engine *e) {
     if (const char *v = getenv("MLGGD_DP_MAINLINE")) e->dp_mainline = atoi(v);
     if (const char *v = getenv("MLGGD_DP_STOPEV")) e->dp_stopev = atoi(v);
-    return MLGGD_OK;
+    if (const char *v = getenv("MLGGD_DP_AR_SHARD")) e->ar_shard = atoi(v) != 0;
 }
 // one rank's block -> every rank's slot r of dst (on the communication stream, or on `st`)
 static int gather_one(mlggd_engine *e, const float *src, float *dst, size_t count, hipStream_t st = nullptr) {
@@ -1055,7 +1079,7 @@ static int run_loss(mlggd_engine *e, const Bunch &bn, float nf, float inv_n, Col
                                (size_t)e->Dp);
             return launch_check("k_accum");
         }
-        NCCLCHK(g_rccl.AllReduce(e->colsum, e->colsum, (size_t)e->Dp, 7, 0, e->comm, e->stream));
+        NCCLCHK(g_rccl.AllReduce(e->colsum, e->colsum, (size_t)e->Dp, 7, 0, e->stat_comm ? e->stat_comm : e->comm, e->stream));
         colsum_in = e->colsum;
     }
     if (cs == CS_ACCUMULATE) return MLGGD_OK;
@@ -1158,6 +1182,8 @@ static int fake_world_prepass(mlggd_engine *e, int sample0, float nf, float inv_
 // sample0: index of the minibatch's first row in the resident chunk (only the emulated world needs it).
 static int run_step(mlggd_engine *e, int sample0, bool prestaged = false, const Bunch *next = nullptr) {
     const int L = e->L, B = e->B, Bp = e->Bp;
+    e->stop_ev_next = nullptr;  // see run_forward
+    e->stop_ev_attached = false;
     const bool dp = e->comm != nullptr || e->fake_world;  // a 1-rank communicator still takes the exchange path (tests)
     const bool gather = dp && e->dp_mode >= 1;
     const int n_global = B * e->world;
@@ -1254,8 +1280,13 @@ static int run_step(mlggd_engine *e, int sample0, bool prestaged = false, const 
         if (dp && !gather) {
             if (!take_stop(e)) HIPCHK(hipEventRecord(e->ev_grad[l], dws));
             HIPCHK(hipStreamWaitEvent(e->comm_stream, e->ev_grad[l], 0));
-            if (e->fake_world) {  // sum over the emulated ranks: what the all-reduce delivers
+            if (e->fake_world) {  // sum over the emulated ranks: what the all-reduce (or the union of the reduce-scatter blocks) delivers
                 if (e->world > 1) CHK(launch_accum(e->G[l], e->Gpre[l], e->G[l], (size_t)Kp * Np, e->comm_stream));
+            } else if (e->ar_shard) {
+                // reduce-scatter over blocks of weight rows (shard_rows[l] tile rows of 64 per rank; G_l is allocated
+                // with world x block rows, the rows past Kp stay zero): this rank receives the sum of ITS block, in place
+                const size_t blk = (size_t)e->shard_rows[l] * 64 * Np;
+                NCCLCHK(g_rccl.ReduceScatter(e->G[l], e->G[l] + (size_t)e->rank * blk, blk, e->comm, e->comm_stream));
             } else {
                 NCCLCHK(g_rccl.AllReduce(e->G[l], e->G[l], (size_t)Kp * Np, 7, 0, e->comm, e->comm_stream));
             }
@@ -1344,16 +1375,47 @@ static int run_step(mlggd_engine *e, int sample0, bool prestaged = false, const 
         for (int l = L - 1; l >= 1; l--) {
             HIPCHK(hipStreamWaitEvent(dws, e->ev_red[l], 0));
             ProfScope ps(e, KC_UPDATE, l, dws);
-            const size_t n4 = (size_t)e->lsp[l - 1] * e->lsp[l] / 4;
-            hipLaunchKernelGGL(k_apply_update, dim3(2048), dim3(256), 0, dws, e->W[l], e->dW[l], e->G[l], n4, nf,
-                               e->cfg.momentum, e->cfg.lrate, e->cfg.weightcost);
-            CHK(launch_check("k_apply_update"));
+            const int Kp = e->lsp[l - 1], Np = e->lsp[l];
+            // kernUpdatedelta + kernAccSum (DevFunc.cu:490-507,427-443) on the rows [row0, row0 + rows) of W_l: the
+            // whole matrix (MLGGD_DP_AR_SHARD=0), or the block of weight rows this rank received the summed gradient
+            // of -- delta is kept for that block only.  The emulated world has every block's sum in G_l and applies
+            // the blocks of all its ranks one after the other (they are disjoint: the union is the whole update).
+            const int r_lo = !e->ar_shard ? 0 : e->fake_world ? 0 : e->rank;
+            const int r_hi = !e->ar_shard ? 0 : e->fake_world ? e->world - 1 : e->rank;
+            for (int r = r_lo; r <= r_hi; r++) {
+                const int row0 = e->ar_shard ? r * e->shard_rows[l] * 64 : 0;
+                const int row1 = e->ar_shard ? (row0 + e->shard_rows[l] * 64 < Kp ? row0 + e->shard_rows[l] * 64 : Kp) : Kp;
+                if (row1 <= row0) continue;  // a block that lies entirely in the pad rows
+                const size_t off = (size_t)row0 * Np, n4 = (size_t)(row1 - row0) * Np / 4;
+                const size_t blocks = (n4 + 255) / 256;
+                hipLaunchKernelGGL(k_apply_update, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, dws,
+                                   e->W[l] + off, e->dW[l] + off, e->G[l] + off, n4, nf, e->cfg.momentum, e->cfg.lrate,
+                                   e->cfg.weightcost);
+                CHK(launch_check("k_apply_update"));
+            }
         }
         HIPCHK(hipStreamWaitEvent(dws, e->ev_bias_red, 0));
         BiasJobs jobs = make_bias_jobs(e);
         hipLaunchKernelGGL(k_bias_apply, dim3((jobs.total + 255) / 256), dim3(256), 0, dws, jobs, nf,
                            e->cfg.momentum, e->cfg.lrate);
         CHK(launch_check("k_bias_apply"));
+        if (e->ar_shard && !e->fake_world) {
+            // the updated W blocks travel back: all-gather in place, layer 1 first and -- like the sharded factor
+            // mode -- on the MAIN stream (the next forward pass waits for it first; no hand-off to the communication
+            // stream and back), the upper layers on the communication stream beside forward_1, each with its event
+            const bool w1_main = e->dp_mainline && !two;
+            HIPCHK(hipEventRecord(e->ev_dw_done, dws));
+            HIPCHK(hipStreamWaitEvent(e->comm_stream, e->ev_dw_done, 0));
+            for (int l = 1; l < L; l++) {
+                const size_t count = (size_t)e->shard_rows[l] * 64 * e->lsp[l];
+                hipStream_t st = (l == 1 && w1_main) ? e->stream : e->comm_stream;
+                NCCLCHK(g_rccl.AllGather(e->W[l] + (size_t)e->rank * count, e->W[l], count, 7, e->comm, st));
+                if (st == e->comm_stream) {
+                    HIPCHK(hipEventRecord(e->ev_W[l], e->comm_stream));
+                    e->ev_W_pending[l] = true;
+                }
+            }
+        }
     }
     if (two) {  // the next forward pass (and any host read-back on the main stream) waits for the updates
         HIPCHK(hipEventRecord(e->ev_upd, dws));
@@ -1494,6 +1556,7 @@ int mlggd_destroy(mlggd_handle e) {
     if (e->stream) hipStreamSynchronize(e->stream);
     if (e->comm_stream) hipStreamSynchronize(e->comm_stream);
     if (e->dw_stream) hipStreamSynchronize(e->dw_stream);
+    if (e->stat_comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->stat_comm);
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
     for (void *p : e->allocs) hipFree(p);
     if (e->chunk_in) hipFree(e->chunk_in);
@@ -2074,14 +2137,20 @@ int mlggd_debug_tensor(mlggd_handle e, const char *name, int layer, float *dst, 
 
 // ---- data parallel
 // gradient buffers (layer_ydedx / layer_sumdedx of BP_WorkSpace) only exist on the all-reduce path
+static int shard_alloc(mlggd_engine *e);
 static int allreduce_alloc(mlggd_engine *e) {
+    // reduce-scatter form: the block table of the sharded factor mode (shard_rows[l] tile rows per rank, W_l grown
+    // to world x block rows, one event per layer for the W all-gathers); G_l gets the same rows so that every rank's
+    // block of the reduce-scatter has the same size (rows past Kp are never written: they stay zero)
+    if (e->ar_shard) CHK(shard_alloc(e));
     size_t gbn = 0;
     for (int l = 1; l < e->L; l++) gbn += e->lsp[l];
     CHK(dev_alloc(e, &e->gb_all, gbn));
     e->gb_all_count = gbn;
     size_t off = 0;
     for (int l = e->L - 1; l >= 1; l--) {
-        CHK(dev_alloc(e, &e->G[l], (size_t)e->lsp[l - 1] * e->lsp[l]));
+        const size_t rows = e->ar_shard ? (size_t)e->shard_rows[l] * 64 * e->world : (size_t)e->lsp[l - 1];
+        CHK(dev_alloc(e, &e->G[l], (rows > (size_t)e->lsp[l - 1] ? rows : (size_t)e->lsp[l - 1]) * e->lsp[l]));
         e->gb[l] = e->gb_all + off;
         off += e->lsp[l];
         HIPCHK(hipEventCreateWithFlags(&e->ev_grad[l], hipEventDisableTiming));
@@ -2180,6 +2249,12 @@ int mlggd_comm_init(mlggd_handle e, const void *id, int world_size, int rank) {
     e->world = world_size;
     e->rank = rank;
     e->dp_mode = mode;
+    dp_knobs(e);
+    if (const char *v = getenv("MLGGD_DP_STAT_COMM"))
+        if (atoi(v) != 0 && e->cfg.MLflag == 1) {
+            if (!g_rccl.CommSplit) return fail(MLGGD_ERR_COMM, "MLGGD_DP_STAT_COMM=1: librccl has no ncclCommSplit");
+            NCCLCHK(g_rccl.CommSplit(e->comm, 0, rank, &e->stat_comm, nullptr));  // collective: every rank takes this branch (same env, same MLflag)
+        }
     CHK(create_comm_stream(e));
     if (e->dp_mode >= 1) {
         CHK(gather_alloc(e));
@@ -2208,6 +2283,7 @@ int mlggd_debug_fake_world(mlggd_handle e, int world_size, int mode) {
     e->rank = world_size - 1;  // the rank that takes the real exchange path; the others are emulated before it
     e->fake_world = true;
     e->dp_mode = mode == 2 ? 0 : mode == 1 ? 2 : 1;
+    dp_knobs(e);
     CHK(create_comm_stream(e));
     CHK(dev_alloc(e, &e->colsum_tot, e->Dp));
     if (mode == 2) {

@@ -142,6 +142,52 @@ def test_emulated_world_equals_one_device_with_the_global_bunch(pkg, pyoracle, s
     eng.close()
 
 
+@pytest.mark.parametrize("harness", ["one_rank_communicator", "emulated_world_of_4"])
+@pytest.mark.parametrize("mode", ["gather", "shard", "allreduce"])
+def test_dp_launch_order_knobs_do_not_change_a_bit(pkg, synth, monkeypatch, mode, harness):
+    """MLGGD_DP_MAINLINE (critical-path collectives on the main stream), MLGGD_DP_STOPEV (events riding on
+    the producing kernel's dispatch packet) and, for the all-reduce arm, MLGGD_DP_AR_SHARD (reduce-scatter -> update
+    of the rank's block -> all-gather of W, against all-reduce + full update) change WHERE and WHEN work is enqueued,
+    never what is computed (and MLGGD_DP_STAT_COMM only which communicator carries the 257-float statistic): every arm
+    must leave bit-identical weights, biases and alpha -- through a real 1-rank
+    RCCL communicator (streams, events, RCCL calls) and in an emulated world of 4 ranks (different rows per rank,
+    uneven blocks).  A premature send or a skipped wait shows up here as a different bit.  The defaults themselves
+    rest on these one-GPU rehearsals: nothing has run between two GPUs."""
+    monkeypatch.setenv("MLGGD_DP_MODE", mode)
+    ls, B, steps, world = [40 * 5, 160, 96, 40], 64, 4, 4
+    ws, bs = synth.make_weights(ls, seed=8)
+    n = steps * (world if harness == "emulated_world_of_4" else 1) * B
+    inp, targ = synth.make_frames(n, 40, 5, seed=10)
+
+    def run(env):
+        for k in ("MLGGD_DP_MAINLINE", "MLGGD_DP_STOPEV", "MLGGD_DP_AR_SHARD", "MLGGD_DP_STAT_COMM"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = pkg.BPGpu(1, 0, ls, B, *HP, ws, bs, 1.2, 1)
+        if harness == "emulated_world_of_4":
+            eng.fake_world(world, sharded=mode == "shard", allreduce=mode == "allreduce")
+        else:
+            eng.comm_init(pkg.comm_unique_id(), 1, 0)
+        assert eng.train(inp, targ) == steps
+        w, b = eng.returnWeights()
+        out = [x.copy() for x in w + b] + [eng.scalefactor().copy()]
+        eng.close()
+        return out
+
+    base = run({})
+    arms = [{"MLGGD_DP_MAINLINE": "0"}, {"MLGGD_DP_STOPEV": "0"}, {"MLGGD_DP_MAINLINE": "0", "MLGGD_DP_STOPEV": "0"}]
+    if mode == "allreduce":
+        arms += [{"MLGGD_DP_AR_SHARD": "0"}, {"MLGGD_DP_AR_SHARD": "0", "MLGGD_DP_STOPEV": "0"}]
+    if harness == "one_rank_communicator":
+        # the ML statistic's all-reduce on a communicator of its own (ncclCommSplit): same sum, another queue
+        arms += [{"MLGGD_DP_STAT_COMM": "1"}]
+    for env in arms:
+        got = run(env)
+        for i, (x, y) in enumerate(zip(got, base)):
+            assert np.array_equal(x, y), (env, i)
+
+
 @pytest.mark.parametrize("world", [2, 4, 8])
 @pytest.mark.parametrize("ml,beta", [(0, 2.0), (1, 1.2)])
 def test_emulated_world_with_the_fine_grained_factor_exchange(pkg, pyoracle, synth, monkeypatch, ml, beta, world):
