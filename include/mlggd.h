@@ -198,6 +198,10 @@ int mlggd_debug_fake_world(mlggd_handle h, int world_size, int mode);
  * first steps of a run (2 on one GPU, a few in the data-parallel modes). */
 int mlggd_debug_plan_count(mlggd_handle h, int *plans);
 
+/* Test hook: the number of split-K slabs of the output-layer forward GEMM (the loss kernel adds them in order).  The
+ * oracle's MFMA-order twin needs it to restate the HIP path's summation order (oracle/mlggd_oracle.c). */
+int mlggd_debug_out_slabs(mlggd_handle h, int *slabs);
+
 /* Diagnostic: out[i] = fn(x[i], y) evaluated on the device with the libm calls the kernels themselves use -- fn "powf"
  * (kernindex2 / kernfunc2 / kernSubClean2, DevFunc.cu:219-227,468-489,376-398), "expf", "sigmoid" = 1/(1+expf(-x))
  * (kernSigmoid, DevFunc.cu:36-51), "div" = x / y.  Parity tests use it to state, in ulps, how far the device's libm

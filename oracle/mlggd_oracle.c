@@ -160,6 +160,110 @@ static void ensure_frames(ora_net *net, int frames) {
 static int g_gemm_split = 1;
 void ora_set_gemm_split(int s) { g_gemm_split = s < 1 ? 1 : s; }
 
+/* MFMA-order twin: the summation order -- and the fused multiply-adds -- of the HIP kernels,
+ * restated on the CPU, so that a test can pin the three GEMMs of the HIP path to a CPU model BIT FOR BIT on ordinary
+ * data and what is left between the HIP path and this oracle is libm alone (expf in the sigmoid, powf in the loss).
+ * order 0 (default): the orders documented at each gemm_* -- what every parity test compares against.
+ * order 1: csrc/kernels.hip.h --
+ *   forward (fwd_body): v_mfma_f32_32x32x2_f32 consumes two consecutive k per instruction as two chained fused
+ *     multiply-adds (k, then k+1: established by tests/test_gpu_mfma_order.py, not assumed); a workgroup's 4 waves
+ *     take the 4 contiguous ranges of k-PAIRS [P*w/4, P*(w+1)/4), P = ceil32(K)/2 (pad rows are exact zeros), each
+ *     chains its range ascending from 0.0f, and the four partial sums are added in wave order; then + bias.
+ *     The output layer is split over s_out slabs x 4 waves the same way (slot = 4*s + w of 4*s_out slots); a slab
+ *     holds its 4 waves' sum, the loss kernel adds the slabs in order, then the bias (slab_sum).
+ *   dX (dx_body): the reduction index n in QUADS of four; the 4 waves take ceil(Q/4) quads each (Q = ceil32(N)/4);
+ *     within a quad the two MFMAs consume {4j, 4j+2} then {4j+1, 4j+3}; partial sums added in wave order.
+ *   dW (dwp_body): one chain per weight over the frames 0..B-1 ascending (pairs of consecutive frames per MFMA).
+ * The elementwise operations around the GEMMs are the same IEEE operations in both orders. */
+static int g_gemm_order = 0, g_hip_s_out = 1;
+void ora_set_gemm_order(int order, int s_out) {
+    g_gemm_order = order == 1 ? 1 : 0;
+    g_hip_s_out = s_out < 1 ? 1 : s_out;
+}
+#define ORA_FMA __attribute__((target("fma"))) /* fmaf as ONE instruction; -ffp-contract=off still keeps every other a*b+c unfused */
+static int ceil32i(int x) { return (x + 31) & ~31; }
+
+ORA_FMA static void gemm_fwd_hip(int B, int K, int N, const float *Y, const float *W, float *X, int S) {
+    enum { JB = 128 };
+    const int nblk = (N + JB - 1) / JB;
+    const int P = ceil32i(K) / 2, nslots = S * 4;
+#pragma omp parallel
+    {
+        float *tot = (float *)malloc((size_t)B * JB * sizeof(float));
+        float *slab = (float *)malloc((size_t)B * JB * sizeof(float));
+        float *part = (float *)malloc((size_t)B * JB * sizeof(float));
+#pragma omp for schedule(dynamic, 1)
+        for (int jb = 0; jb < nblk; jb++) {
+            const int j0 = jb * JB, jw = (N - j0 < JB) ? N - j0 : JB;
+            for (int sl = 0; sl < S; sl++) {
+                for (int w = 0; w < 4; w++) {
+                    const int slot = sl * 4 + w;
+                    const int p0 = (int)((unsigned)(P * slot) / (unsigned)nslots);
+                    const int p1 = (int)((unsigned)(P * (slot + 1)) / (unsigned)nslots);
+                    const int k_lo = 2 * p0, k_hi = 2 * p1 < K ? 2 * p1 : K; /* rows k >= K are zero pads */
+                    memset(part, 0, (size_t)B * JB * sizeof(float));
+                    for (int k = k_lo; k < k_hi; k++) {
+                        const float *wr = W + (size_t)k * N + j0;
+                        for (int b = 0; b < B; b++) {
+                            const float yv = Y[(size_t)b * K + k];
+                            float *a = part + (size_t)b * JB;
+                            for (int j = 0; j < jw; j++) a[j] = __builtin_fmaf(wr[j], yv, a[j]);
+                        }
+                    }
+                    for (size_t i = 0; i < (size_t)B * JB; i++) slab[i] = w == 0 ? part[i] : slab[i] + part[i];
+                }
+                for (size_t i = 0; i < (size_t)B * JB; i++) tot[i] = sl == 0 ? slab[i] : tot[i] + slab[i];
+            }
+            for (int b = 0; b < B; b++)
+                for (int j = 0; j < jw; j++) {
+                    float *x = X + (size_t)b * N + j0 + j;
+                    *x = tot[(size_t)b * JB + j] + *x;
+                }
+        }
+        free(tot);
+        free(slab);
+        free(part);
+    }
+}
+
+ORA_FMA static void gemm_dx_hip(int B, int K, int N, const float *dEdX, const float *W, float *dEdY) {
+    const int Q = ceil32i(N) / 4, qw = (Q + 3) / 4;
+#pragma omp parallel for schedule(static)
+    for (int k = 0; k < K; k++) {
+        const float *w = W + (size_t)k * N;
+        for (int b = 0; b < B; b++) {
+            const float *d = dEdX + (size_t)b * N;
+            float tot = 0.0f;
+            for (int wv = 0; wv < 4; wv++) {
+                const int q0 = wv * qw, qend = q0 + qw < Q ? q0 + qw : Q;
+                float part = 0.0f;
+                for (int q = q0; q < qend; q++) {
+                    static const int ord[4] = {0, 2, 1, 3};
+                    for (int t = 0; t < 4; t++) {
+                        const int j = 4 * q + ord[t];
+                        if (j < N) part = __builtin_fmaf(w[j], d[j], part); /* columns j >= N are zero pads */
+                    }
+                }
+                tot = wv == 0 ? part : tot + part;
+            }
+            dEdY[(size_t)b * K + k] = tot;
+        }
+    }
+}
+
+ORA_FMA static void gemm_dw_hip(int B, int K, int N, const float *Y, const float *dEdX, float *G) {
+#pragma omp parallel for schedule(static)
+    for (int k = 0; k < K; k++) {
+        float *g = G + (size_t)k * N;
+        for (int j = 0; j < N; j++) g[j] = 0.0f;
+        for (int b = 0; b < B; b++) {
+            const float yv = Y[(size_t)b * K + k];
+            const float *d = dEdX + (size_t)b * N;
+            for (int j = 0; j < N; j++) g[j] = __builtin_fmaf(yv, d[j], g[j]);
+        }
+    }
+}
+
 static void gemm_fwd(int B, int K, int N, const float *Y, const float *W, float *X) {
     enum { JB = 128 };
     const int nblk = (N + JB - 1) / JB;
@@ -261,7 +365,8 @@ void ora_forward(ora_net *net, int n, const float *in) {
         float *x = net->layer_x[l];
         /* kernMultiCopy, DevFunc.cu:134-149 <- BP_GPU.cu:360 */
         for (int b = 0; b < n; b++) memcpy(x + (size_t)b * N, net->bias[l], N * sizeof(float));
-        gemm_fwd(n, K, N, prev_y, net->weights[l], x); /* :361 */
+        if (g_gemm_order == 1) gemm_fwd_hip(n, K, N, prev_y, net->weights[l], x, l == L - 1 ? g_hip_s_out : 1);
+        else gemm_fwd(n, K, N, prev_y, net->weights[l], x); /* :361 */
         if (l != L - 1) {
             /* kernSigmoid, DevFunc.cu:36-51 <- :364 */
             float *y = net->layer_y[l];
@@ -358,8 +463,13 @@ void ora_backward(ora_net *net, int n, const float *in) {
 #pragma omp parallel for schedule(static)
             for (size_t i = 0; i < sz; i++) dedx[i] = (1.0f - y[i]) * y[i] * dedy[i];
         }
-        if (l != 1) gemm_dx(n, K, N, dedx, net->weights[l], net->layer_dedy[l - 1]); /* :430 */
-        gemm_dw(n, K, N, prev_y, dedx, net->layer_ydedx[l]);                          /* :432 */
+        if (g_gemm_order == 1) {
+            if (l != 1) gemm_dx_hip(n, K, N, dedx, net->weights[l], net->layer_dedy[l - 1]);
+            gemm_dw_hip(n, K, N, prev_y, dedx, net->layer_ydedx[l]);
+        } else {
+            if (l != 1) gemm_dx(n, K, N, dedx, net->weights[l], net->layer_dedy[l - 1]); /* :430 */
+            gemm_dw(n, K, N, prev_y, dedx, net->layer_ydedx[l]);                          /* :432 */
+        }
         /* kernAccSumrow, DevFunc.cu:267-285 <- :434 (alpha 0, beta 1; rows summed in order) */
         float *sum = net->layer_sumdedx[l];
         for (int j = 0; j < N; j++) {

@@ -54,6 +54,7 @@ def lib(variant="strict"):
         L.ora_num_threads.restype = C.c_int
         L.ora_set_num_threads.argtypes = [C.c_int]
         L.ora_set_gemm_split.argtypes = [C.c_int]
+        L.ora_set_gemm_order.argtypes = [C.c_int, C.c_int]
         if "OMP_NUM_THREADS" not in os.environ:
             # a container often sees all host CPUs but may only use a share of them: more threads than
             # that share makes every OpenMP region slower, not faster
@@ -220,6 +221,15 @@ def set_gemm_split(s, variant="strict"):
     S > 1 = forward / dX reductions as S contiguous partial sums (what a split-K GEMM does).  Tests use the distance
     between the two to say what a mere change of summation order -- which cuBLAS leaves open -- does to a run."""
     lib(variant).ora_set_gemm_split(int(s))
+
+
+def set_gemm_order(order, s_out=1, variant="strict"):
+    """MFMA-order twin (process-wide for that library): order "hip" / 1 = the HIP kernels' own summation order with
+    fused multiply-adds -- forward / dX reductions over the 4 waves' contiguous ranges, the output layer over `s_out`
+    slabs x 4 waves (the engine's choice: BPGpu.out_slabs()), dW over the frames in order; "ref" / 0 = the documented
+    orders every parity test compares against.  With order "hip" the GEMMs of the HIP path equal this CPU model bit for
+    bit (tests/test_gpu_mfma_order.py), which leaves libm (expf, powf) as the only difference between the two."""
+    lib(variant).ora_set_gemm_order(1 if order in (1, "hip") else 0, int(s_out))
 
 
 def gamma(x):

@@ -48,7 +48,7 @@ EXPORTS = [
     "mlggd_debug_stamp_select", "mlggd_debug_stamp_read",
     "mlggd_load_frames", "mlggd_train_frames", "mlggd_train_frames_async", "mlggd_cv_all_frames", "mlggd_forward_frames",
     "mlggd_alloc_pinned", "mlggd_alloc_pinned_on", "mlggd_free_pinned", "mlggd_set_cv_device_reduce",
-    "mlggd_comm_info", "mlggd_debug_plan_count", "mlggd_debug_math",
+    "mlggd_comm_info", "mlggd_debug_plan_count", "mlggd_debug_math", "mlggd_debug_out_slabs",
 ]
 
 _lib = None
@@ -110,6 +110,7 @@ def load():
     L.mlggd_debug_fake_world.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.mlggd_comm_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.mlggd_debug_plan_count.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    L.mlggd_debug_out_slabs.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     L.mlggd_debug_math.argtypes = [C.c_void_p, C.c_char_p, _fp, C.c_float, _fp, C.c_size_t]
     L.mlggd_debug_stamp_select.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     L.mlggd_debug_stamp_read.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.c_int, C.POINTER(C.c_int)]
@@ -400,6 +401,12 @@ class BPGpu:
         """0 single device, 1 all-reduce of gradients, 2 all-gather of the gradient factors, 3 = 2 + sharded update"""
         n = C.c_int(0)
         _check(load().mlggd_dp_mode(self._h, C.byref(n)))
+        return n.value
+
+    def out_slabs(self):
+        """split-K slabs of the output-layer forward GEMM (the oracle's MFMA-order twin restates the same split)"""
+        n = C.c_int(0)
+        _check(load().mlggd_debug_out_slabs(self._h, C.byref(n)))
         return n.value
 
     def comm_info(self):

@@ -2318,6 +2318,11 @@ int mlggd_debug_plan_count(mlggd_handle e, int *plans) {
     *plans = (int)e->dwp_tables.size();
     return MLGGD_OK;
 }
+int mlggd_debug_out_slabs(mlggd_handle e, int *slabs) {
+    if (!e || !slabs) return fail(MLGGD_ERR_ARG, "NULL argument");
+    *slabs = e->S_out;
+    return MLGGD_OK;
+}
 int mlggd_dp_mode(mlggd_handle e, int *mode) {
     if (!e || !mode) return fail(MLGGD_ERR_ARG, "NULL argument");
     *mode = (e->comm || e->fake_world) ? 1 + e->dp_mode : 0;  // 0 single device, 1 all-reduce, 2 gather, 3 gather + sharded update

@@ -12,9 +12,21 @@ reference keeps its sample data (the GPU box has no reference tree) and a gen_ra
 names one the reference does not ship.
 
 Epochs 1, 2 and 11 run back to back (epoch 11 resumes from `mlp.10.wts`, here a copy of `mlp.2.wts`: epochs 3-10 are
-the epoch-2 form again).  Checked against the same three epochs driven from Python -- the host IO code for chunk / sample
-order, the CPU oracle for the math (TC/BP_GPU.cu:408-423, TC/BPtrain.cc:94-139), an INDEPENDENT chain: the oracle's
-epoch 2 resumes from the oracle's own epoch-1 file -- weights files to 5e-5 of max|W|, the three CV log lines to 1e-4."""
+the epoch-2 form again), each resuming from the EXECUTABLE's own previous weights file, as under finetune.pl.  Every
+epoch is checked against the same epoch driven from Python from the same input files -- the host IO code for chunk /
+sample order, the CPU oracle for the math (TC/BP_GPU.cu:408-423, TC/BPtrain.cc:94-139).
+
+Bounds.  The shipped objective is NOT a smooth function of the weights: at beta = 1 the gradient is sgn(e) / sum|e|, it
+jumps by 2 / sum|e| wherever an error crosses zero, and a perturbation of relative size p flips ~p x 33,000 signs per
+step, each worth ~1e-4 of max|W| -- so ANY rounding-level difference grows by an e-fold per step until it saturates.
+Measured on the oracle ALONE on this test's data (r04): its summation-order twin (split 4) is 1.9e-7 of max|W| away after
+2 steps, 3.0e-4 after 5, 6.5e-3 after 40 (biases 5.6e-2 of their small maximum); the FMA build 2.6e-3 -- and the HIP path
+6.6e-3 / 5.3e-2.  (beta = 1.2, same data, 40 steps: 2.0e-5.)  So the weight files are held to K_TWIN = 4 x the larger
+distance of the oracle's own twins (split 4, and the MFMA-order twin: the HIP kernels' exact summation order on the
+CPU), measured in the test on the same epoch, and the three CV log lines to 1e-4 relative -- the north_star figure -- OR
+K_TWIN x the twins' distance where that is larger.  The first two steps of an epoch, before the growth sets in, are
+held to the plain 5e-5 by tests/test_gpu_parity.py::test_baseline_net_two_steps[1-1.0] and the loss chain to 0 ulp by
+tests/test_gpu_loss_ulps.py."""
 import json
 import os
 import re
@@ -49,7 +61,7 @@ def test_bptrain_sigmoid_as_finetune_pl_drives_it_epochs_1_2_11(pkg, pyoracle, t
     tc = tmp_path / "Train_code_ML_GGD"
     (tc / "pretraining_weights").mkdir(parents=True)
     (tc / "MLGGD1").mkdir()                                        # finetune.pl:42-43
-    (tc / "ORA").mkdir()                                           # the oracle chain's own weights files
+    (tc / "ORA").mkdir()                                           # scratch of the Python-side run
     tools = tmp_path / "tools_pfile"
     tools.mkdir()
     # synthetic stand-ins for tools_pfile/train_{noisy,clean}.pfile + train_noisy.norm: 10 sentences (the script's
@@ -66,66 +78,82 @@ def test_bptrain_sigmoid_as_finetune_pl_drives_it_epochs_1_2_11(pkg, pyoracle, t
     subprocess.check_call([os.path.join(hostlib.HOST, "gen_rand_net"), "5", *map(str, ls), str(init.parent), str(init),
                            "1", "2", "5"], stdout=subprocess.DEVNULL)
 
+    probe = pkg.BPGpu(1, 0, ls, B, 0.1, 0.9, 1e-5, *hostlib.read_wts(str(init), ls), 1.0, 1)
+    s_out = probe.out_slabs()                                      # split of the output-layer GEMM: the MFMA-order twin restates it
+    probe.close()
+    K_TWIN = 4.0
     cwd = os.getcwd()
     os.chdir(tc)                                                   # the script's paths are relative to its directory
     try:
-        prev_ora = None
         for epoch in (1, 2, 11):
             argv = argvs[epoch - 1]
             kv = dict(a.split("=", 1) for a in argv)
             assert kv["outwts_file"] == "./MLGGD1/mlp.%d.wts" % epoch
             if epoch == 11:                                        # epochs 3..10 are not run: stand in for mlp.10.wts
                 shutil.copy("./MLGGD1/mlp.2.wts", "./MLGGD1/mlp.10.wts")
-                shutil.copy("./ORA/mlp.2.wts", "./ORA/mlp.10.wts")
             assert not os.path.exists(kv["outwts_file"])           # finetune.pl:49,88,126 would skip the epoch otherwise
             res = subprocess.run([exe] + argv, capture_output=True, text=True, timeout=600)
             assert res.returncode == 0, res.stdout + res.stderr
             assert "all finish!" in res.stdout
             log = open(kv["log_file"]).read()
 
-            # the same epoch from Python; the oracle resumes from ITS OWN previous file
-            okv = dict(kv, outwts_file="./ORA/unused.wts", log_file="./ORA/unused.log")
-            if epoch > 1:
-                okv["initwts_file"] = kv["initwts_file"].replace("./MLGGD1/", "./ORA/")
-            io = hostlib.HostIO(**okv)
+            # the same epoch from Python, from the same input files
+            io = hostlib.HostIO(**dict(kv, outwts_file="./ORA/unused.wts", log_file="./ORA/unused.log"))
             lrate = float(io.para("lrate"))                        # atof -> float, as Interface.cc parses it
             assert abs(lrate - 0.1 * 0.9 ** max(0, epoch - 10)) < 1e-7
             assert int(io.para("init_randem_seed")) == 27870775 + 345 * (epoch - 1)   # finetune.pl:31,86
-            w0, b0 = hostlib.read_wts(okv["initwts_file"], ls)
-            ora = pyoracle.OracleNet(ls, B, lrate, float(io.para("momentum")), float(io.para("weightcost")),
-                                     float(io.para("shapefactor")), int(io.para("MLflag")), w0, b0)
+            w0, b0 = hostlib.read_wts(kv["initwts_file"], ls)
             starts, total = io.plan(kv["train_sent_range"])
             order = io.shuffle(len(starts))
-            steps = 0
-            for n, ci in enumerate(order):
-                inp, tg = io.read_chunk(ci, ls[0], dim, int(kv["traincache"]))
+            chunks = [io.read_chunk(ci, ls[0], dim, int(kv["traincache"])) for ci in order]
+            for n, (inp, _) in enumerate(chunks):
                 assert "Starting chunk %d of %d containing %d samples." % (n + 1, len(starts), len(inp)) in log
-                steps += ora.train(inp, tg)
-            assert steps >= 35
             cvs, cvtotal = io.plan(kv["cv_sent_range"], cv=True)
-            sq = ab = ll = np.float32(0)
-            for ci in range(len(cvs)):
-                inp, tg = io.read_chunk(ci, ls[0], dim, int(kv["traincache"]), cv=True)
-                sq += np.float32(ora.cv_sqerr(inp, tg))
-                ab += np.float32(ora.cv_abserr(inp, tg))
-                ll += np.float32(ora.cv_loglik(inp, tg))
+            cvchunks = [io.read_chunk(ci, ls[0], dim, int(kv["traincache"]), cv=True) for ci in range(len(cvs))]
+            hp = (lrate, float(io.para("momentum")), float(io.para("weightcost")), float(io.para("shapefactor")),
+                  int(io.para("MLflag")))
             io.close()
-            wo, bo = ora.get_weights()
-            hostlib.write_wts("./ORA/mlp.%d.wts" % epoch, wo, bo)
+
+            def oracle_epoch(split=1, order="ref"):
+                pyoracle.set_gemm_split(split)
+                pyoracle.set_gemm_order(order, s_out)
+                try:
+                    ora = pyoracle.OracleNet(ls, B, *hp, w0, b0)
+                    steps = sum(ora.train(inp, tg) for inp, tg in chunks)
+                    sq = ab = ll = np.float32(0)
+                    for inp, tg in cvchunks:
+                        sq += np.float32(ora.cv_sqerr(inp, tg))
+                        ab += np.float32(ora.cv_abserr(inp, tg))
+                        ll += np.float32(ora.cv_loglik(inp, tg))
+                    w, b = ora.get_weights()
+                    ora.close()
+                    return {"w": w, "b": b, "cv": [float(sq) / cvtotal, float(ab) / cvtotal, float(ll) / cvtotal], "steps": steps}
+                finally:
+                    pyoracle.set_gemm_split(1)
+                    pyoracle.set_gemm_order("ref")
+
+            def dist(a, r):
+                return {"w": max(relmax(x, y) for x, y in zip(a["w"], r["w"])),
+                        "b": max(relmax(x, y) for x, y in zip(a["b"], r["b"])),
+                        "cv": [abs(g_ - w_) / abs(w_) for g_, w_ in zip(a["cv"], r["cv"])]}
+
+            ref = oracle_epoch()
+            assert ref["steps"] >= 35
             ws, bs = hostlib.read_wts(kv["outwts_file"], ls)
-            dw = max(relmax(ws[l], wo[l]) for l in range(4))
-            db = max(relmax(bs[l], bo[l]) for l in range(4))
             got = [float(re.search(pat + r": (-?[\d.]+)", log).group(1)) for pat in
                    ("CV over. squared error", "CV over. square root squared error", "CV2 over. CV log likelihood")]
-            want = [float(sq) / cvtotal, float(ab) / cvtotal, float(ll) / cvtotal]
-            print("finetune.pl epoch %2d (lrate %.6g, %d steps): weights %.1e biases %.1e of max | CV lines %s vs oracle %s"
-                  % (epoch, lrate, steps, dw, db, got, ["%.6f" % w for w in want]))
-            assert dw < 5e-5 and db < 5e-5, (epoch, dw, db)
-            for g_, w_ in zip(got, want):
-                assert abs(g_ - w_) <= 1e-4 * abs(w_) + 1e-6, (epoch, got, want)
-            if prev_ora is not None:                               # training moved the weights: not a copy of the input
-                assert any(not np.array_equal(a, b) for a, b in zip(wo, prev_ora))
-            prev_ora = wo
-            ora.close()
+            d_hip = dist({"w": ws, "b": bs, "cv": got}, ref)
+            twins = {"split 4": dist(oracle_epoch(split=4), ref), "MFMA order": dist(oracle_epoch(order="hip"), ref)}
+            yard = {"w": max(t["w"] for t in twins.values()), "b": max(t["b"] for t in twins.values()),
+                    "cv": [max(t["cv"][i] for t in twins.values()) for i in range(3)]}
+            fmt = lambda d: "weights %.1e biases %.1e | CV %.1e %.1e %.1e" % (d["w"], d["b"], *d["cv"])
+            print("finetune.pl epoch %2d (lrate %.6g, %d steps): HIP vs oracle: %s" % (epoch, lrate, ref["steps"], fmt(d_hip)))
+            for name, t in twins.items():
+                print("      oracle twin (%s) vs oracle: %s" % (name, fmt(t)))
+            assert d_hip["w"] <= K_TWIN * yard["w"] and d_hip["b"] <= K_TWIN * yard["b"], (epoch, d_hip, yard)
+            for i in range(3):
+                assert d_hip["cv"][i] <= max(1e-4, K_TWIN * yard["cv"][i]) + 1e-6, (epoch, i, d_hip, yard)
+            assert d_hip["w"] < 5e-2 and max(d_hip["cv"]) < 2e-3          # and never an order of magnitude beyond what was measured
+            assert any(not np.array_equal(a, b) for a, b in zip(ws, w0))  # training moved the weights: not a copy of the input
     finally:
         os.chdir(cwd)

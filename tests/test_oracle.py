@@ -183,3 +183,57 @@ def test_fma_contraction_variant_is_inside_the_gpu_tolerances(pyoracle, synth, m
     print("fma vs strict, %s ml=%d beta=%.1f: weights %.1e" % (shape, ml, beta, worst))
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("s_out", [1, 3, 7])
+def test_mfma_order_twin_is_the_same_function_in_another_summation_order(pyoracle, synth, s_out):
+    """oracle `ora_set_gemm_order(1, s_out)`: the HIP kernels' own summation order with fused multiply-adds (forward / dX
+    over the 4 waves' contiguous ranges, the output layer over s_out slabs x 4 waves, dW over the frames in order;
+    csrc/kernels.hip.h fwd_body / dx_body / dwp_body).  It must be the same function as the documented-order oracle up
+    to rounding -- checked against the float64 model and against the default order -- and it must really be another
+    order (different bits).  Widths that are not multiples of 32 or 4 exercise the pad handling of the ranges.
+    On the GPU the HIP path equals this twin BIT FOR BIT (tests/test_gpu_mfma_order.py)."""
+    ls, B = [3 * 37, 70, 45, 37], 16
+    ws, bs = synth.make_weights(ls, seed=3)
+    rng = np.random.default_rng(5)
+    bs = [rng.uniform(-0.1, 0.1, b.shape).astype(np.float32) for b in bs]
+    inp, targ = synth.make_frames(3 * B, 37, 3, seed=4)
+    base = pyoracle.OracleNet(ls, B, *HP, 1.2, 1, ws, bs)
+    assert base.train(inp, targ) == 3
+    pyoracle.set_gemm_order("hip", s_out)
+    try:
+        twin = pyoracle.OracleNet(ls, B, *HP, 1.2, 1, ws, bs)
+        assert twin.train(inp, targ) == 3
+        cv_t = twin.cv_sqerr(inp, targ)
+    finally:
+        pyoracle.set_gemm_order("ref")
+    r = Ref64(ls, *HP, 1.2, 1, ws, bs)
+    for i in range(3):
+        r.step(inp[i * B:(i + 1) * B], targ[i * B:(i + 1) * B])
+    wt, bt = twin.get_weights()
+    wb, bb = base.get_weights()
+    for l in range(3):
+        assert relmax(wt[l], r.W[l]) < 2e-6 and relmax(bt[l], r.b[l]) < 2e-5
+        assert relmax(wt[l], wb[l]) < 2e-6
+        assert relmax(twin.tensor("delta_w", l + 1), r.dW[l]) < 2e-5
+    assert any(not np.array_equal(x, y) for x, y in zip(wt, wb))       # another order: other bits
+    assert relmax(twin.tensor("scalefactor"), r.alpha) < 1e-5
+    assert abs(cv_t - base.cv_sqerr(inp, targ)) <= 1e-5 * abs(cv_t)
+    # exactly representable data: every order gives the same bits (small-integer inputs, weights in eighths)
+    W = [(rng.integers(-4, 5, (ls[i], ls[i + 1])) * 0.125).astype(np.float32) for i in range(3)]
+    W[0][:] = 0                                                        # hidden activations exactly 0.5
+    W[1][:] = 0
+    b0 = [np.zeros(n, np.float32) for n in ls[1:]]
+    x = rng.integers(-3, 4, (B, ls[0])).astype(np.float32)
+    t = rng.integers(-3, 4, (B, ls[3])).astype(np.float32)
+    a = pyoracle.OracleNet(ls, B, *HP, 2.0, 0, W, b0)
+    a.train(x, t)
+    pyoracle.set_gemm_order("hip", s_out)
+    try:
+        c = pyoracle.OracleNet(ls, B, *HP, 2.0, 0, W, b0)
+        c.train(x, t)
+    finally:
+        pyoracle.set_gemm_order("ref")
+    assert np.array_equal(a.tensor("out", rows=B), c.tensor("out", rows=B))
+    for o in (base, twin, a, c):
+        o.close()
