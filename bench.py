@@ -29,16 +29,31 @@ dispatch's own begin/end timestamps, comparable with rocprofv3's average); `ml_g
 (MLflag=1, beta=1.2) measured the same way in the same invocation.  `dp_breakdown` (untimed post-passes, one per
 kernel class): device time of the rank's own kernels per step against the step's wall time -- the difference is the
 exposed part of the exchange.
+
+Time budget (`--budget-s`, default 240 s from process start): the headline always runs; every further leg (dp_breakdown,
+N > 1 `loss_vs_oracle`, `dp_arms.*` -- all-reduce first, it is the exchange BASELINE.json names --, `ml_ggd`, the 1-rank
+rehearsal, the CPU baseline and its parity legs) is started only if its estimated cost still fits, else it is listed
+under `skipped` (rank 0 decides, the decision is broadcast).  The headline is copied to stderr the moment it exists;
+on SIGTERM rank 0 prints what it has to stdout (marked `incomplete`) and exits 0, so a run that outlives the caller's
+limit still delivers its line.  A watchdog that fires AFTER the headline also prints the partial line but exits 4.
+
+N > 1 parity (`loss_vs_oracle`, BASELINE.json's "loss-vs-ref delta"): a fresh engine on the same communicator layout
+trains K = 20 global minibatches, rank 0 scores a held-out chunk and compares with the CPU oracle run at bunchsize
+world x B on the same rows (rank-major: rank r owns rows [rB, (r+1)B) of every global minibatch, SURVEY 8e);
+`replicas_identical` = the CRC of every rank's weights and biases agrees (gloo all-gather).
 """
 import argparse
 import json
 import os
+import signal
 import socket
 import subprocess
 import sys
 import threading
 import time
+import zlib
 
+T0 = time.time()  # the budget of --budget-s counts from here (interpreter start-up and imports included)
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 PKG = "speech-enhancement-based-on-a-maximum-likelihood-criterion_amd"
@@ -75,6 +90,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-ml", action="store_true", help="skip the ml_ggd (configs[2]) measurement")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--budget-s", type=float, default=240.0,
+                    help="seconds from process start within which optional legs may still be STARTED (module docstring)")
     ap.add_argument("--dry-launch", action="store_true",
                     help="start the ranks, rendezvous over gloo, report rank/world and exit before touching a GPU")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="self-launcher: seconds before the ranks are killed")
@@ -124,17 +141,30 @@ def launch_ranks(args, argv):
     t.start()
     deadline = time.time() + args.launch_timeout
     first_bad, grace = None, None
+    term = {"at": None}
+
+    def on_term(signum, frame):  # the caller's time limit: pass it on; rank 0 prints what it has and the ranks leave
+        if term["at"] is None:
+            term["at"] = time.time()
+            for p in procs:  # exactly the processes started above
+                if p.poll() is None:
+                    p.terminate()
+
+    signal.signal(signal.SIGTERM, on_term)
     while True:
         codes = [p.poll() for p in procs]
         if all(c is not None for c in codes):
             break
         bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
-        if bad and first_bad is None:
+        if bad and first_bad is None and term["at"] is None:
             # the peers' own watchdogs get a chance to say where they were
             first_bad, grace = bad[0], time.time() + float(os.environ.get("MLGGD_BENCH_GRACE_S", "20"))
         now = time.time()
-        if (grace is not None and now > grace) or now > deadline:
-            why = ("rank %d exited with status %d" % first_bad) if first_bad else ("no result after %.0f s" % args.launch_timeout)
+        if now > deadline and term["at"] is None:
+            sys.stderr.write("bench launcher: no result after %.0f s; asking the ranks to finish (SIGTERM)\n" % args.launch_timeout)
+            on_term(None, None)
+        if (grace is not None and now > grace) or (term["at"] is not None and now > term["at"] + 15):
+            why = ("rank %d exited with status %d" % first_bad) if first_bad else "the ranks did not leave within 15 s of SIGTERM"
             sys.stderr.write("bench launcher: %s; stopping the remaining ranks\n" % why)
             for p in procs:  # exactly the processes started above
                 if p.poll() is None:
@@ -147,6 +177,8 @@ def launch_ranks(args, argv):
     codes = [p.returncode for p in procs]
     if any(codes):
         sys.stderr.write("bench launcher: rank exit codes %s\n" % codes)
+    if term["at"] is not None:  # asked to finish: the run counts as delivered if rank 0 printed its (partial) line and left with 0
+        return codes[0] if codes[0] is not None else 1
     return next((c for c in codes if c), 0) if first_bad is None else first_bad[1]
 
 
@@ -234,6 +266,11 @@ def dry_launch(rank, world, local_rank):
 
 # ----------------------------------------------------------------------------------------------------------------
 def rank_main(args):
+    # SIGTERM is blocked in this thread BEFORE anything that starts threads is imported (numpy's BLAS pool, torch, gloo:
+    # they inherit the mask), so the signal stays pending until term_waiter's sigwait takes it -- a process-directed
+    # signal goes to ANY thread that does not block it, and the default action there would end the rank without its line
+    if not args.dry_launch:
+        signal.pthread_sigmask(signal.SIG_BLOCK, {signal.SIGTERM})
     import datetime
     import importlib
 
@@ -369,22 +406,56 @@ def rank_main(args):
         return out
 
     out = {}
-    state = {"headline_done": False}
+    state = {"headline_done": False, "phase": "start"}
+    skipped = []
+
+    def deliver(reason):
+        """rank 0: the line as far as it has got, marked incomplete (watchdog, SIGTERM)"""
+        out["incomplete"] = reason
+        if skipped:
+            out["skipped"] = skipped
+        print(json.dumps(out), file=real_stdout, flush=True)
 
     def last_words(phase):
-        # rank 0, watchdog fired: if the headline was already measured (a secondary measurement got stuck), still
-        # deliver it -- with the reason -- and report success for THAT; otherwise nothing to print, status 3
+        # watchdog fired.  If the headline was already measured (a secondary leg got stuck) rank 0 still delivers it,
+        # with the reason -- but the process status says that something hung: 4 (3 = nothing to deliver)
         if rank == 0 and state["headline_done"]:
-            out["incomplete"] = "watchdog: stuck in phase '%s' (%s)" % (phase, last_coll["what"])
-            print(json.dumps(out), file=real_stdout, flush=True)
-            return 0
-        return 0 if state["headline_done"] else 3
+            deliver("watchdog: stuck in phase '%s' (%s)" % (phase, last_coll["what"]))
+        return 4 if state["headline_done"] else 3
 
     wd.on_fire = last_words
 
+    def term_waiter():
+        # SIGTERM = the caller's time limit.  Waited for in a thread of its own (the signal is blocked in every thread,
+        # so it stays pending until sigwait takes it): the main thread may sit inside a HIP / gloo call for minutes,
+        # where a Python-level handler would never get to run.
+        signal.sigwait({signal.SIGTERM})
+        sys.stderr.write("bench.py rank %d: SIGTERM in phase '%s'\n" % (rank, wd.phase))
+        if rank == 0 and state["headline_done"]:
+            deliver("SIGTERM in phase '%s': the legs after it were not run" % wd.phase)
+        sys.stderr.flush()
+        os._exit(0 if state["headline_done"] else 143)
+
+    threading.Thread(target=term_waiter, daemon=True).start()
+
+    cost = {"measure": 20.0}  # seconds one engine + ramp + windows leg took (the headline sets it)
+
+    def fits(leg, estimate_s):
+        """May an optional leg still be started?  Rank 0 decides (elapsed time differs per rank), everyone follows."""
+        ok = [time.time() - T0 + estimate_s <= args.budget_s]
+        if world > 1:
+            last_coll["what"] = "gloo broadcast (budget decision for '%s')" % leg
+            dist.broadcast_object_list(ok, src=0)
+        if not ok[0]:
+            skipped.append({"leg": leg, "estimate_s": round(estimate_s, 1), "elapsed_s": round(time.time() - T0, 1),
+                            "budget_s": args.budget_s})
+        return ok[0]
+
+    t_leg = time.time()
     eng = make_engine(ml, beta, args.dp_mode)
     mode = eng.dp_mode()
     head = measure(eng, "headline", 512)
+    cost["measure"] = time.time() - t_leg
 
     roofline = None
     if not args.no_kernel_timing:
@@ -478,63 +549,145 @@ def rank_main(args):
         "rendezvous": "gloo" if world > 1 else None,
         "launched_by": "bench.py (child ranks)" if os.environ.get("MLGGD_BENCH_LAUNCHED") else
                        ("external launcher" if world > 1 else "direct"),
+        "budget_s": args.budget_s,
     })
     state["headline_done"] = True
-    if not args.no_kernel_timing:
+    if rank == 0:  # an early copy for whoever watches stderr: a run cut short after this point is not an empty run
+        sys.stderr.write("bench.py headline after %.0f s (early copy; the line on stdout follows at the end): %s\n"
+                         % (time.time() - T0, json.dumps(out)))
+        sys.stderr.flush()
+    if os.environ.get("MLGGD_BENCH_TEST_HANG_AFTER_HEADLINE") == str(rank):  # tests/test_bench_launcher.py
+        wd.enter("test hang after the headline", 60, "nothing: test hook")
+        time.sleep(3600)
+    if not args.no_kernel_timing and fits("dp_breakdown", 5):
         out["dp_breakdown"] = breakdown(eng, head["ms_per_step"], "headline")
+    eng.close()
+    eng = None
 
-    if args.loss == "mmse" and not args.no_ml:
-        # BASELINE.json configs[2] in the same invocation: ML-GGD loss (MLflag=1, beta=1.2), same data, same steps
-        eng.close()
-        eng = make_engine(1, 1.2, args.dp_mode)
-        m_ml = measure(eng, "ml_ggd", 256)
-        out["ml_ggd"] = {"workload": "the same net and data with the ML-GGD loss (MLflag=1, beta=1.2): BASELINE.json configs[2]",
-                         "value": round(m_ml["value"], 1), "unit": "frames/s", "ms_per_step": round(m_ml["ms_per_step"], 5),
-                         "window_ms_min": min(m_ml["window_ms"]), "window_ms_max": max(m_ml["window_ms"]),
-                         "step_roofline_frac": round(m_ml["value"] * fpf / (world * MFMA_F32_PEAK_TFLOPS * 1e12), 4)}
-        if dp and not args.no_kernel_timing:
-            out["ml_ggd"]["dp_breakdown"] = breakdown(eng, m_ml["ms_per_step"], "ml_ggd")
+    # ---- N-rank parity (also in the 1-rank rehearsal): K global minibatches, then the numbers the reference logs
+    def dp_parity(ml_, beta_, dp_mode, label, env=None):
+        kpar = min(20, nb)
+        for k, v in (env or {}).items():
+            os.environ[k] = v
+        try:
+            e2 = make_engine(ml_, beta_, dp_mode)
+        finally:
+            for k in (env or {}):
+                os.environ.pop(k, None)
+        wd.enter("%s: %d parity steps" % (label, kpar), 300, "RCCL collectives of the training steps")
+        assert e2.train_resident(0, kpar * B) == kpar
+        e2.sync()
+        w_, b_ = e2.returnWeights()
+        crc = zlib.crc32(b"".join(np.ascontiguousarray(x).tobytes() for x in list(w_) + list(b_)))
+        crcs = [crc]
+        if world > 1:
+            wd.enter("%s: replica check" % label, 120, "gloo all_gather_object")
+            crcs = [None] * world
+            dist.all_gather_object(crcs, crc)
+        res = {"steps": kpar, "oracle_bunchsize": world * B, "replicas_identical": len(set(crcs)) == 1,
+               "dp_mode": DP_MODE_NAME[e2.dp_mode()]}
+        if rank == 0:
+            wd.enter("%s: oracle at bunchsize %d" % (label, world * B), 900)
+            from oracle import pyoracle  # the checker; nothing here is timed
+            pyoracle.lib().ora_set_num_threads(pyoracle.usable_cpus())  # the other ranks are parked in a barrier
+            cin, ctarg = synth.make_frames(1000, 257, 11, seed=77)
+            sq, ab, ll = e2.cv_all(cin, ctarg)
+            rows = [(inp, targ)] + [synth.make_frames(nb * B, 257, 11, seed=synth.DEFAULT_SEED + 1 + r) for r in range(1, world)]
+            ora = pyoracle.OracleNet(ls, world * B, 0.1, 0.9, 1e-5, beta_, ml_, ws, bs)
+            for t in range(kpar):  # global minibatch t: rank r's bunch t in rows [rB, (r+1)B)
+                ora.train_bunch(np.concatenate([x[t * B:(t + 1) * B] for x, _ in rows]),
+                                np.concatenate([y[t * B:(t + 1) * B] for _, y in rows]))
+            osq, oab = ora.cv_sqerr(cin, ctarg), ora.cv_abserr(cin, ctarg)
+            res.update({"cv_sqerr_rel": abs(sq - osq) / abs(osq), "cv_abserr_rel": abs(ab - oab) / abs(oab)})
+            if ml_:
+                oll = ora.cv_loglik(cin, ctarg)
+                alpha, oalpha = e2.scalefactor(), ora.tensor("scalefactor")
+                res["cv_loglik_rel"] = abs(ll - oll) / abs(oll)
+                res["alpha_relmax"] = float(np.abs(alpha - oalpha).max() / np.abs(oalpha).max())
+            wo, _ = ora.get_weights()
+            res["weights_relmax"] = max(float(np.abs(a_ - o_).max() / np.abs(o_).max()) for a_, o_ in zip(w_, wo))
+            ora.close()
+            res = {k: (float("%.2e" % v) if isinstance(v, float) else v) for k, v in res.items()}
+        e2.close()
+        wd.enter("%s: barrier after the oracle" % label, 900, "gloo barrier (rank 0 is running the CPU oracle)")
+        barrier("barrier after the parity leg")
+        return res
 
+    est_parity = cost["measure"] + 10 + 0.25 * world * min(20, nb)  # the oracle: ~0.2 s per 1,024-frame step
+    # (the stub engine of the tests has no oracle-grade numbers to offer; MLGGD_BENCH_STUB_PARITY=1 runs the leg's control flow anyway)
+    want_parity = dp and (not args.no_cpu_baseline or os.environ.get("MLGGD_BENCH_STUB_PARITY") == "1")
+    if want_parity and fits("loss_vs_oracle", est_parity):
+        out["loss_vs_oracle"] = dp_parity(ml, beta, args.dp_mode, "loss_vs_oracle")
+
+    def measure_arm(label, ml_, beta_, dp_mode, env=None, with_breakdown=True):
+        for k, v in (env or {}).items():
+            os.environ[k] = v
+        try:
+            e2 = make_engine(ml_, beta_, dp_mode)
+        finally:
+            for k in (env or {}):
+                os.environ.pop(k, None)
+        m2 = measure(e2, label, 256)
+        r = {"value": round(m2["value"], 1), "unit": "frames/s", "ms_per_step": round(m2["ms_per_step"], 5),
+             "window_ms_min": min(m2["window_ms"]), "window_ms_max": max(m2["window_ms"]),
+             "step_roofline_frac": round(m2["value"] * fpf / (world * MFMA_F32_PEAK_TFLOPS * 1e12), 4)}
+        if dp:
+            r["dp_exchange"] = DP_EXCHANGE[e2.dp_mode()]
+        if env:
+            r["env"] = dict(env)
+        if with_breakdown and not args.no_kernel_timing:
+            r["dp_breakdown"] = breakdown(e2, m2["ms_per_step"], label)
+        e2.close()
+        return r
+
+    est_arm = 1.3 * cost["measure"] + 5
+    arms = {}
+    arm_specs = []
     if dp and not args.no_dp_arms:
-        # The other gradient exchanges on the same ranks, same data, same windows: BASELINE.json names the all-reduce of
-        # the weight gradients; the engine's default is the factor all-gather.  Every arm the
-        # shape allows is reported so that one multi-GPU run decides the default from a measurement.
-        arms = {}
-        eng.close()
-        eng = None
-        # "gather_other_granularity": the factor exchange with the OTHER setting of MLGGD_DP_FINE than the one in force
-        # (0 = four grouped exchanges and one dW launch, the default; 1 = every factor sent the moment it exists + the
-        # dW launch split in two): the default rests on a 1-rank measurement and a link model, so the first multi-GPU
-        # run measures both
+        # The other gradient exchanges on the same ranks, same data, same windows, ordered by what they decide: first
+        # BASELINE.json's own exchange (the all-reduce of the weight gradients: reduce-scatter -> update of the rank's
+        # block -> all-gather of W), then the engine's default and its sharded form, then the launch-order switches
+        # whose defaults rest on one-GPU rehearsals (MLGGD_DP_FINE, MLGGD_DP_MAINLINE, MLGGD_DP_AR_SHARD).
         fine_default = os.environ.get("MLGGD_DP_FINE")
-        for arm in ("allreduce", "gather", "shard", "gather_other_granularity"):
-            if arm == DP_MODE_NAME[mode]:
-                arms[arm] = {"value": out["value"], "ms_per_step": out["ms_per_step"], "same_as": "headline"}
-                continue
-            other = arm == "gather_other_granularity"
-            if other:
-                os.environ["MLGGD_DP_FINE"] = "0" if fine_default == "1" else "1"
-            try:
-                e2 = make_engine(ml, beta, "gather" if other else arm)
-            except pkg.MlggdError as ex:  # the shape rules the factor exchange out (every rank takes this branch)
-                arms[arm] = {"unavailable": str(ex)[:160]}
-                continue
-            finally:
-                if other:
-                    if fine_default is None:
-                        os.environ.pop("MLGGD_DP_FINE", None)
-                    else:
-                        os.environ["MLGGD_DP_FINE"] = fine_default
-            m2 = measure(e2, "dp arm " + arm, 256)
-            arms[arm] = {"value": round(m2["value"], 1), "unit": "frames/s", "ms_per_step": round(m2["ms_per_step"], 5),
-                         "window_ms_min": min(m2["window_ms"]), "window_ms_max": max(m2["window_ms"]),
-                         "dp_exchange": DP_EXCHANGE[e2.dp_mode()]}
-            if other:
-                arms[arm]["MLGGD_DP_FINE"] = 0 if fine_default == "1" else 1
-            if not args.no_kernel_timing:
-                arms[arm]["dp_breakdown"] = breakdown(e2, m2["ms_per_step"], "dp arm " + arm)
-            e2.close()
+        arm_specs = [("allreduce", "allreduce", None), ("gather", "gather", None), ("shard", "shard", None),
+                     ("gather_other_granularity", "gather", {"MLGGD_DP_FINE": "0" if fine_default == "1" else "1"}),
+                     ("headline_mode_without_mainline", DP_MODE_NAME[mode], {"MLGGD_DP_MAINLINE": "0"}),
+                     ("allreduce_unsharded_update", "allreduce", {"MLGGD_DP_AR_SHARD": "0"})]
+
+    def run_arm(name, dp_mode, env):
+        if name == DP_MODE_NAME[mode]:
+            arms[name] = {"value": out["value"], "ms_per_step": out["ms_per_step"], "same_as": "headline"}
+            return
+        if not fits("dp_arms." + name, est_arm):
+            return
+        try:
+            arms[name] = measure_arm("dp arm " + name, ml, beta, dp_mode, env)
+        except pkg.MlggdError as ex:  # the shape rules the factor exchange out (every rank takes this branch)
+            arms[name] = {"unavailable": str(ex)[:160]}
+        if name == "gather_other_granularity" and "value" in arms[name]:
+            arms[name]["MLGGD_DP_FINE"] = int(env["MLGGD_DP_FINE"])
+
+    if arm_specs:
         out["dp_arms"] = arms
+        run_arm(*arm_specs[0])  # north_star's exchange before anything else optional
+
+    if args.loss == "mmse" and not args.no_ml and fits("ml_ggd", est_arm):
+        # BASELINE.json configs[2] in the same invocation: ML-GGD loss (MLflag=1, beta=1.2), same data, same steps
+        out["ml_ggd"] = dict({"workload": "the same net and data with the ML-GGD loss (MLflag=1, beta=1.2): BASELINE.json configs[2]"},
+                             **measure_arm("ml_ggd", 1, 1.2, args.dp_mode, with_breakdown=dp))
+        if want_parity and fits("ml_ggd.loss_vs_oracle", est_parity):
+            out["ml_ggd"]["loss_vs_oracle"] = dp_parity(1, 1.2, args.dp_mode, "ml_ggd.loss_vs_oracle")
+        if dp and fits("ml_ggd.stat_comm", est_arm):
+            # the 257-float statistic on a communicator of its own (ncclCommSplit): does it stop queueing behind the
+            # factor / weight collectives?  (first thing to try once two GPUs are available)
+            try:
+                out["ml_ggd"]["stat_comm"] = measure_arm("ml_ggd with MLGGD_DP_STAT_COMM=1", 1, 1.2, args.dp_mode,
+                                                         {"MLGGD_DP_STAT_COMM": "1"}, with_breakdown=False)
+            except pkg.MlggdError as ex:
+                out["ml_ggd"]["stat_comm"] = {"unavailable": str(ex)[:160]}
+
+    for spec in arm_specs[1:]:
+        run_arm(*spec)
 
     if world == 1 and not dp and not args.no_dp_rehearsal and not stub:
         # What the data-parallel exchange path costs BEFORE any link time, measured in the driver's own single-GPU run:
@@ -543,10 +696,17 @@ def rank_main(args):
         reh = {"what": "this workload through a 1-rank RCCL communicator: the exchange path's fixed cost without links; "
                        "single-GPU step for comparison: ms_per_step above", "ms_per_step": {}}
         try:
-            eng.close()
-            eng = None
-            for arm in ("gather", "shard", "allreduce"):
-                e2 = make_engine(ml, beta, arm, comm=True)
+            for arm, env in (("allreduce", None), ("gather", None), ("shard", None),
+                             ("allreduce_unsharded_update", {"MLGGD_DP_AR_SHARD": "0"})):
+                if not fits("dp_rehearsal_1rank." + arm, est_arm):
+                    continue
+                for k, v in (env or {}).items():
+                    os.environ[k] = v
+                try:
+                    e2 = make_engine(ml, beta, arm.split("_")[0], comm=True)
+                finally:
+                    for k in (env or {}):
+                        os.environ.pop(k, None)
                 m2 = measure(e2, "1-rank rehearsal " + arm, 256)
                 reh["ms_per_step"][arm] = round(m2["ms_per_step"], 5)
                 reh.setdefault("window_ms", {})[arm] = [min(m2["window_ms"]), max(m2["window_ms"])]
@@ -555,7 +715,7 @@ def rank_main(args):
             reh["error"] = str(ex)[:200]
         out["dp_rehearsal_1rank"] = reh
 
-    if rank == 0 and world == 1 and not dp and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not dp and not args.no_cpu_baseline and fits("cpu_baseline", 2.2 * args.cpu_seconds + 8):
         wd.enter("cpu baseline + loss_vs_oracle", 900)
         from oracle import pyoracle  # CPU oracle = the checker, timed here only as the reported CPU baseline
         ora = pyoracle.OracleNet(ls, B, 0.1, 0.9, 1e-5, beta, ml, ws, bs)
@@ -571,11 +731,31 @@ def rank_main(args):
         out["cpu_baseline"] = {"value": round(n * B / cdt, 1), "unit": "frames/s", "cores": pyoracle.num_threads(),
                                "kind": "port", "sample": "%d steps over the same %d-frame minibatches (oracle, OpenMP, threads = usable CPU share)"
                                % (n, B), "gpu_over_cpu": round(head["value"] / (n * B / cdt), 1)}
+        step_s = cdt / n
 
         # BASELINE.json's "loss-vs-ref delta": a fresh engine trains exactly the steps the oracle has just been timed
         # on (the oracle here is the CHECKER; nothing below is timed), then both score a held-out synthetic chunk with
-        # the numbers the reference logs after an epoch (BPtrain.cc:131-138).  configs[2] (ML-GGD) gets a shorter run.
-        def loss_delta(ml_, beta_, ora_, n_):
+        # the numbers the reference logs after an epoch (BPtrain.cc:131-138).  The ML-GGD legs get a shorter run.
+        cin, ctarg = synth.make_frames(1000, 257, 11, seed=77)
+
+        def scores(o_or_eng, ml_, is_engine):
+            if is_engine:
+                sq, ab, ll = o_or_eng.cv_all(cin, ctarg)
+                al = o_or_eng.scalefactor() if ml_ else None
+            else:
+                sq, ab = o_or_eng.cv_sqerr(cin, ctarg), o_or_eng.cv_abserr(cin, ctarg)
+                ll = o_or_eng.cv_loglik(cin, ctarg) if ml_ else 0.0
+                al = o_or_eng.tensor("scalefactor").copy() if ml_ else None
+            return sq, ab, ll, al
+
+        def delta(a, r, ml_):
+            d = {"cv_sqerr_rel": abs(a[0] - r[0]) / abs(r[0]), "cv_abserr_rel": abs(a[1] - r[1]) / abs(r[1])}
+            if ml_:
+                d["cv_loglik_rel"] = abs(a[2] - r[2]) / abs(r[2])
+                d["alpha_relmax"] = float(np.abs(a[3] - r[3]).max() / np.abs(r[3]).max())
+            return {k: float("%.2e" % v) for k, v in d.items()}
+
+        def engine_after(ml_, beta_, n_):
             chk = pkg.BPGpu(synth.DEFAULT_SEED, local_rank, ls, B, 0.1, 0.9, 1e-5, ws, bs, beta_, ml_)
             chk.train(inp[:B], targ[:B])
             chk.train(inp[:B], targ[:B])
@@ -585,59 +765,71 @@ def rank_main(args):
                 m = min(n_ - done, nb)
                 chk.train_resident(0, m * B)
                 done += m
-            cin, ctarg = synth.make_frames(1000, 257, 11, seed=77)
-            sq, ab, ll = chk.cv_all(cin, ctarg)
-            osq, oab = ora_.cv_sqerr(cin, ctarg), ora_.cv_abserr(cin, ctarg)
-            d = {"steps": n_ + 2, "cv_sqerr_rel": abs(sq - osq) / abs(osq), "cv_abserr_rel": abs(ab - oab) / abs(oab)}
-            if ml_:
-                oll = ora_.cv_loglik(cin, ctarg)
-                alpha, oalpha = chk.scalefactor(), ora_.tensor("scalefactor")
-                d["cv_loglik_rel"] = abs(ll - oll) / abs(oll)
-                d["alpha_relmax"] = float(np.abs(alpha - oalpha).max() / np.abs(oalpha).max())
+            r = scores(chk, ml_, True)
+            s_out = chk.out_slabs() if hasattr(chk, "out_slabs") else 1
             chk.close()
-            return {k: (v if k == "steps" else float("%.2e" % v)) for k, v in d.items()}
+            return r, s_out
 
-        def oracle_after(ml_, beta_, n_, split=1):
-            pyoracle.set_gemm_split(split)
+        def oracle_after(ml_, beta_, n_, split=1, order="ref", s_out=1, variant="strict"):
+            pyoracle.set_gemm_split(split, variant)
+            pyoracle.set_gemm_order(order, s_out, variant)
             try:
-                o = pyoracle.OracleNet(ls, B, 0.1, 0.9, 1e-5, beta_, ml_, ws, bs)
+                o = pyoracle.OracleNet(ls, B, 0.1, 0.9, 1e-5, beta_, ml_, ws, bs, variant=variant)
                 o.train_bunch(inp[:B], targ[:B])
                 o.train_bunch(inp[:B], targ[:B])
                 for i in range(n_):
                     o.train_bunch(inp[(i % nb) * B:(i % nb + 1) * B], targ[(i % nb) * B:(i % nb + 1) * B])
+                r = scores(o, ml_, False)
+                o.close()
+                return r
             finally:
-                pyoracle.set_gemm_split(1)
-            return o
+                pyoracle.set_gemm_split(1, variant)
+                pyoracle.set_gemm_order("ref", 1, variant)
 
-        def twin_delta(ml_, beta_, ora_, n_):
-            """The yardstick for loss_vs_oracle: the SAME oracle with another, equally valid GEMM summation order
-            (cuBLAS leaves the order open; oracle/mlggd_oracle.c "Summation-order twin") after the same steps."""
-            tw = oracle_after(ml_, beta_, n_, split=4)
-            cin, ctarg = synth.make_frames(1000, 257, 11, seed=77)
-            a = (tw.cv_sqerr(cin, ctarg), tw.cv_abserr(cin, ctarg), tw.cv_loglik(cin, ctarg), tw.tensor("scalefactor"))
-            b = (ora_.cv_sqerr(cin, ctarg), ora_.cv_abserr(cin, ctarg), ora_.cv_loglik(cin, ctarg), ora_.tensor("scalefactor"))
-            tw.close()
-            d = {"cv_sqerr_rel": abs(a[0] - b[0]) / abs(b[0]), "cv_abserr_rel": abs(a[1] - b[1]) / abs(b[1]),
-                 "cv_loglik_rel": abs(a[2] - b[2]) / abs(b[2]),
-                 "alpha_relmax": float(np.abs(a[3] - b[3]).max() / np.abs(b[3]).max())}
-            d = {k: float("%.2e" % v) for k, v in d.items()}
-            d["what"] = "oracle with forward/dX reductions as 4 contiguous partial sums vs the oracle itself: what a change of GEMM summation order alone does over these steps"
-            return d
+        def parity_leg(ml_, beta_, n_, ref=None):
+            """HIP vs oracle after the same steps, next to the YARDSTICKS: the same oracle in other, equally valid
+            arithmetic -- forward / dX reductions as 4 resp. 7 contiguous partial sums (what any split-K GEMM does; cuBLAS
+            leaves the order open), the build with FMA contraction on (nvcc's default), and the MFMA-order twin (the HIP
+            kernels' exact summation order on the CPU: what is left between it and the HIP path is libm alone)."""
+            hip, s_out = engine_after(ml_, beta_, n_)
+            ref = ref if ref is not None else oracle_after(ml_, beta_, n_)
+            leg = {"steps": n_ + 2, "loss_vs_oracle": delta(hip, ref, ml_)}
+            yard = {}
+            for name, kw in (("split4", {"split": 4}), ("split7", {"split": 7}), ("fma_build", {"variant": "fma"}),
+                             ("mfma_order", {"order": "hip", "s_out": s_out})):
+                if time.time() - T0 + (n_ + 2) * step_s * 1.2 > args.budget_s:
+                    skipped.append({"leg": "yardstick %s (ml %d beta %.1f)" % (name, ml_, beta_), "elapsed_s": round(time.time() - T0, 1),
+                                    "budget_s": args.budget_s})
+                    continue
+                yard[name] = delta(oracle_after(ml_, beta_, n_, **kw), ref, ml_)
+            leg["oracle_twins_vs_oracle"] = yard
+            if yard:
+                worst = {k: max(y[k] for y in yard.values()) for k in leg["loss_vs_oracle"]}
+                leg["hip_over_largest_twin"] = {k: (round(leg["loss_vs_oracle"][k] / worst[k], 2) if worst[k] > 0 else None)
+                                                for k in worst}
+            return leg
 
-        out["loss_vs_oracle"] = loss_delta(ml, beta, ora, n)
+        ref_head = scores(ora, ml, False)
         ora.close()
+        head_leg = parity_leg(ml, beta, n, ref=ref_head)
+        out["loss_vs_oracle"] = dict(head_leg["loss_vs_oracle"], steps=head_leg["steps"])
+        out["loss_vs_oracle_twins"] = {"oracle_twins_vs_oracle": head_leg["oracle_twins_vs_oracle"],
+                                       "hip_over_largest_twin": head_leg.get("hip_over_largest_twin")}
         if "ml_ggd" in out:
             n_ml = min(n, 150)
-            ora = oracle_after(1, 1.2, n_ml)
-            out["ml_ggd"]["loss_vs_oracle"] = loss_delta(1, 1.2, ora, n_ml)
-            out["ml_ggd"]["oracle_order_twin_vs_oracle"] = twin_delta(1, 1.2, ora, n_ml)
-            ora.close()
-            # the paper's headline shape factor (README.md:155,165); beta < 1 is the ill-conditioned one (DESIGN.md section 2)
-            ora = oracle_after(1, 0.9, n_ml)
-            out["ml_ggd_beta0.9"] = {"workload": "the same net and data, MLflag=1, beta=0.9 (the paper's best shape factor); parity only, not timed",
-                                     "loss_vs_oracle": loss_delta(1, 0.9, ora, n_ml),
-                                     "oracle_order_twin_vs_oracle": twin_delta(1, 0.9, ora, n_ml)}
-            ora.close()
+            for key, b_, what in (("ml_ggd", 1.2, None),
+                                  ("ml_ggd_beta1.0", 1.0, "the same net and data, MLflag=1, beta=1 -- the objective the reference's finetune.pl ships (TC/finetune.pl:25-26); parity only, not timed"),
+                                  ("ml_ggd_beta0.9", 0.9, "the same net and data, MLflag=1, beta=0.9 (the paper's best shape factor); parity only, not timed")):
+                if time.time() - T0 + 2.5 * (n_ml + 2) * step_s > args.budget_s:
+                    skipped.append({"leg": key + ".loss_vs_oracle", "elapsed_s": round(time.time() - T0, 1), "budget_s": args.budget_s})
+                    continue
+                leg = parity_leg(1, b_, n_ml)
+                tgt = out.setdefault(key, {"workload": what})
+                tgt["loss_vs_oracle"] = dict(leg["loss_vs_oracle"], steps=leg["steps"])
+                tgt["oracle_twins_vs_oracle"] = leg["oracle_twins_vs_oracle"]
+                tgt["hip_over_largest_twin"] = leg.get("hip_over_largest_twin")
+    out["skipped"] = skipped
+    out["elapsed_s"] = round(time.time() - T0, 1)
     wd.enter("teardown", 120, "ncclCommDestroy")
     if eng is not None:
         eng.close()

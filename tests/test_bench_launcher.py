@@ -113,12 +113,17 @@ def test_the_rank_code_runs_end_to_end_on_a_stub_engine(form):
     assert d["timing"]["windows"] == 3 and len(d["timing"]["window_ms"]) == 3
     assert d["timing"]["window_ms_min"] <= d["ms_per_step"] * 4 <= d["timing"]["window_ms_max"]
     assert abs(d["value"] - 2 * 128 * 4 / (d["ms_per_step"] * 4e-3)) <= 1e-3 * d["value"]
-    assert set(d["dp_arms"]) == {"allreduce", "gather", "shard", "gather_other_granularity"}
+    assert list(d["dp_arms"]) == ["allreduce", "gather", "shard", "gather_other_granularity", "headline_mode_without_mainline",
+                                  "allreduce_unsharded_update"]     # north_star's exchange first, the launch-order switches last
     assert d["dp_arms"]["gather"]["same_as"] == "headline" and d["dp_arms"]["gather_other_granularity"]["MLGGD_DP_FINE"] == 1
-    for arm in ("allreduce", "shard", "gather_other_granularity"):
+    for arm in ("allreduce", "shard", "gather_other_granularity", "headline_mode_without_mainline", "allreduce_unsharded_update"):
         assert d["dp_arms"][arm]["value"] > 0 and "dp_breakdown" in d["dp_arms"][arm]
+    assert d["dp_arms"]["headline_mode_without_mainline"]["env"] == {"MLGGD_DP_MAINLINE": "0"}
+    assert d["dp_arms"]["allreduce_unsharded_update"]["env"] == {"MLGGD_DP_AR_SHARD": "0"}
     assert d["dp_breakdown"]["compute_us_by_class"]["fwd"] == 10.0 and "ml_ggd" in d and "dp_breakdown" in d["ml_ggd"]
-    assert "incomplete" not in d
+    assert d["ml_ggd"]["stat_comm"]["env"] == {"MLGGD_DP_STAT_COMM": "1"}
+    assert "incomplete" not in d and d["skipped"] == [] and d["budget_s"] == 240.0
+    assert "bench.py headline after" in r.stderr     # the early copy of the headline
 
 
 def test_stub_engine_arm_the_shape_rules_out_is_reported_not_fatal():
@@ -130,3 +135,72 @@ def test_stub_engine_arm_the_shape_rules_out_is_reported_not_fatal():
     assert d["config"]["dp_mode"] == "allreduce" and d["dp_arms"]["allreduce"]["same_as"] == "headline"
     assert "unavailable" in d["dp_arms"]["gather"] and "unavailable" in d["dp_arms"]["shard"]
     assert "unavailable" in d["dp_arms"]["gather_other_granularity"]
+
+
+def test_stub_engine_two_ranks_take_the_parity_leg():
+    """N > 1 `loss_vs_oracle` (BASELINE.json's "loss-vs-ref delta" in a multi-GPU line): K global minibatches on a fresh
+    engine, CRCs of every rank's weights gathered over gloo, rank 0 runs the CPU oracle at bunchsize world x B on the
+    rank-major rows while the other ranks wait in a barrier.  The stub's numbers mean nothing; the control flow (and the
+    REAL oracle at bunchsize 256 on the rows of both ranks) is what runs here."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "3", "--warmup", "1", "--windows", "2", "--no-dp-arms",
+                        "--hidden", "64", "--nhid", "1", "--stub-engine"], capture_output=True, text=True, timeout=600,
+                       env=_env(MLGGD_BENCH_STUB_PARITY="1"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _json_line(r.stdout)
+    for leg in (d["loss_vs_oracle"], d["ml_ggd"]["loss_vs_oracle"]):
+        assert leg["replicas_identical"] is True and leg["oracle_bunchsize"] == 256 and leg["steps"] == 3
+        assert leg["dp_mode"] == "gather" and "cv_sqerr_rel" in leg and "weights_relmax" in leg
+    assert "cv_loglik_rel" in d["ml_ggd"]["loss_vs_oracle"] and "alpha_relmax" in d["ml_ggd"]["loss_vs_oracle"]
+    assert "cv_loglik_rel" not in d["loss_vs_oracle"]
+
+
+def test_budget_skips_optional_legs_and_says_so():
+    """--budget-s: the headline always runs; a leg whose estimated cost no longer fits is not started and is listed
+    under `skipped` (rank 0 decides, the decision is broadcast so that no rank enters a collective alone)."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "4", "--warmup", "2", "--windows", "3", "--budget-s", "1",
+                        "--stub-engine"], capture_output=True, text=True, timeout=600, env=_env())
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _json_line(r.stdout)
+    assert d["value"] > 0 and d["roofline"] is not None and "incomplete" not in d
+    legs = [x["leg"] for x in d["skipped"]]
+    assert "ml_ggd" in legs and "dp_arms.allreduce" in legs and "dp_arms.shard" in legs and "dp_breakdown" in legs
+    assert "ml_ggd" not in d and d["dp_arms"] == {"gather": {"value": d["value"], "ms_per_step": d["ms_per_step"], "same_as": "headline"}}
+    assert all(x["budget_s"] == 1.0 and x["elapsed_s"] > 0 for x in d["skipped"])
+
+
+def test_sigterm_after_the_headline_still_delivers_the_line():
+    """The caller's time limit arrives as SIGTERM at the launcher: it is passed on to the ranks, rank 0 prints what it
+    has -- the headline, marked `incomplete` -- to stdout and the launch ends with status 0.  (The ranks wait for the
+    signal in a thread of their own: the main thread may sit inside a HIP or gloo call.)"""
+    import signal
+    import time
+    p = subprocess.Popen([sys.executable, BENCH, "--gpus", "2", "--steps", "4", "--warmup", "2", "--windows", "3", "--stub-engine"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                         env=_env(MLGGD_BENCH_TEST_HANG_AFTER_HEADLINE="0"))   # rank 0 parks after its headline
+    err = []
+    deadline = time.time() + 240
+    while time.time() < deadline:                      # wait for the early copy of the headline on stderr
+        line = p.stderr.readline()
+        if not line:
+            break
+        err.append(line)
+        if "bench.py headline after" in line:
+            break
+    assert any("bench.py headline after" in x for x in err), "".join(err)[-2000:]
+    time.sleep(0.5)
+    p.send_signal(signal.SIGTERM)
+    out, rest = p.communicate(timeout=120)
+    assert p.returncode == 0, (p.returncode, rest[-2000:])
+    d = _json_line(out)
+    assert d["value"] > 0 and d["incomplete"].startswith("SIGTERM in phase 'test hang after the headline'")
+
+
+def test_watchdog_after_the_headline_delivers_the_line_but_fails_the_run():
+    """a rank stuck in a secondary leg must not end the launch with status 0.  Rank 0 still prints the
+    headline (marked `incomplete`), every rank leaves with 4, and so does the launcher."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "4", "--warmup", "2", "--windows", "3", "--stub-engine"],
+                       capture_output=True, text=True, timeout=600,
+                       env=_env(MLGGD_BENCH_TEST_HANG_AFTER_HEADLINE="0", MLGGD_BENCH_WATCHDOG_SCALE="0.05", MLGGD_BENCH_GRACE_S="10"))
+    assert r.returncode == 4, (r.returncode, r.stderr[-2000:])
+    d = _json_line(r.stdout)
+    assert d["value"] > 0 and d["incomplete"].startswith("watchdog: stuck in phase 'test hang after the headline'")
