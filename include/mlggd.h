@@ -201,6 +201,10 @@ int mlggd_debug_plan_count(mlggd_handle h, int *plans);
 /* Test hook: the number of split-K slabs of the output-layer forward GEMM (the loss kernel adds them in order).  The
  * oracle's MFMA-order twin needs it to restate the HIP path's summation order (oracle/mlggd_oracle.c). */
 int mlggd_debug_out_slabs(mlggd_handle h, int *slabs);
+/* Test hook: into how many waves' contiguous ranges layer `layer`'s forward GEMM and its dX GEMM (the one that produces
+ * dEdX of layer - 1) cut their reduction: 4 = one 32 x 32 output tile per workgroup (k_fwd / k_dx), 1 = the 64 x 64-tile
+ * kernels for large minibatches (k_fwd64 / k_dx64: one chain per output element).  The MFMA-order twin restates it. */
+int mlggd_debug_gemm_plan(mlggd_handle h, int layer, int *fwd_waves, int *dx_waves);
 
 /* Diagnostic: out[i] = fn(x[i], y) evaluated on the device with the libm calls the kernels themselves use -- fn "powf"
  * (kernindex2 / kernfunc2 / kernSubClean2, DevFunc.cu:219-227,468-489,376-398), "expf", "sigmoid" = 1/(1+expf(-x))

@@ -176,17 +176,27 @@ void ora_set_gemm_split(int s) { g_gemm_split = s < 1 ? 1 : s; }
  *   dW (dwp_body): one chain per weight over the frames 0..B-1 ascending (pairs of consecutive frames per MFMA).
  * The elementwise operations around the GEMMs are the same IEEE operations in both orders. */
 static int g_gemm_order = 0, g_hip_s_out = 1;
+/* waves that share a layer's forward / dX reduction: 4 = k_fwd / k_dx (one 32 x 32 tile per workgroup, reduction over 4
+ * waves), 1 = k_fwd64 / k_dx64 (64 x 64 tile, one chain per output element; csrc/kernels64.hip.h).  The engine reports
+ * its choice per layer (mlggd_debug_gemm_plan). */
+static int g_hip_fwd_waves[ORA_MAXLAYER], g_hip_dx_waves[ORA_MAXLAYER];
 void ora_set_gemm_order(int order, int s_out) {
     g_gemm_order = order == 1 ? 1 : 0;
     g_hip_s_out = s_out < 1 ? 1 : s_out;
+    for (int l = 0; l < ORA_MAXLAYER; l++) g_hip_fwd_waves[l] = g_hip_dx_waves[l] = 4;
+}
+void ora_set_gemm_plan(int layer, int fwd_waves, int dx_waves) {
+    if (layer < 1 || layer >= ORA_MAXLAYER) return;
+    g_hip_fwd_waves[layer] = fwd_waves == 1 ? 1 : 4;
+    g_hip_dx_waves[layer] = dx_waves == 1 ? 1 : 4;
 }
 #define ORA_FMA __attribute__((target("fma"))) /* fmaf as ONE instruction; -ffp-contract=off still keeps every other a*b+c unfused */
 static int ceil32i(int x) { return (x + 31) & ~31; }
 
-ORA_FMA static void gemm_fwd_hip(int B, int K, int N, const float *Y, const float *W, float *X, int S) {
+ORA_FMA static void gemm_fwd_hip(int B, int K, int N, const float *Y, const float *W, float *X, int S, int NW) {
     enum { JB = 128 };
     const int nblk = (N + JB - 1) / JB;
-    const int P = ceil32i(K) / 2, nslots = S * 4;
+    const int P = ceil32i(K) / 2, nslots = S * NW;
 #pragma omp parallel
     {
         float *tot = (float *)malloc((size_t)B * JB * sizeof(float));
@@ -196,8 +206,8 @@ ORA_FMA static void gemm_fwd_hip(int B, int K, int N, const float *Y, const floa
         for (int jb = 0; jb < nblk; jb++) {
             const int j0 = jb * JB, jw = (N - j0 < JB) ? N - j0 : JB;
             for (int sl = 0; sl < S; sl++) {
-                for (int w = 0; w < 4; w++) {
-                    const int slot = sl * 4 + w;
+                for (int w = 0; w < NW; w++) {
+                    const int slot = sl * NW + w;
                     const int p0 = (int)((unsigned)(P * slot) / (unsigned)nslots);
                     const int p1 = (int)((unsigned)(P * (slot + 1)) / (unsigned)nslots);
                     const int k_lo = 2 * p0, k_hi = 2 * p1 < K ? 2 * p1 : K; /* rows k >= K are zero pads */
@@ -226,15 +236,15 @@ ORA_FMA static void gemm_fwd_hip(int B, int K, int N, const float *Y, const floa
     }
 }
 
-ORA_FMA static void gemm_dx_hip(int B, int K, int N, const float *dEdX, const float *W, float *dEdY) {
-    const int Q = ceil32i(N) / 4, qw = (Q + 3) / 4;
+ORA_FMA static void gemm_dx_hip(int B, int K, int N, const float *dEdX, const float *W, float *dEdY, int NW) {
+    const int Q = ceil32i(N) / 4, qw = (Q + NW - 1) / NW;
 #pragma omp parallel for schedule(static)
     for (int k = 0; k < K; k++) {
         const float *w = W + (size_t)k * N;
         for (int b = 0; b < B; b++) {
             const float *d = dEdX + (size_t)b * N;
             float tot = 0.0f;
-            for (int wv = 0; wv < 4; wv++) {
+            for (int wv = 0; wv < NW; wv++) {
                 const int q0 = wv * qw, qend = q0 + qw < Q ? q0 + qw : Q;
                 float part = 0.0f;
                 for (int q = q0; q < qend; q++) {
@@ -365,7 +375,7 @@ void ora_forward(ora_net *net, int n, const float *in) {
         float *x = net->layer_x[l];
         /* kernMultiCopy, DevFunc.cu:134-149 <- BP_GPU.cu:360 */
         for (int b = 0; b < n; b++) memcpy(x + (size_t)b * N, net->bias[l], N * sizeof(float));
-        if (g_gemm_order == 1) gemm_fwd_hip(n, K, N, prev_y, net->weights[l], x, l == L - 1 ? g_hip_s_out : 1);
+        if (g_gemm_order == 1) gemm_fwd_hip(n, K, N, prev_y, net->weights[l], x, l == L - 1 ? g_hip_s_out : 1, g_hip_fwd_waves[l]);
         else gemm_fwd(n, K, N, prev_y, net->weights[l], x); /* :361 */
         if (l != L - 1) {
             /* kernSigmoid, DevFunc.cu:36-51 <- :364 */
@@ -464,7 +474,7 @@ void ora_backward(ora_net *net, int n, const float *in) {
             for (size_t i = 0; i < sz; i++) dedx[i] = (1.0f - y[i]) * y[i] * dedy[i];
         }
         if (g_gemm_order == 1) {
-            if (l != 1) gemm_dx_hip(n, K, N, dedx, net->weights[l], net->layer_dedy[l - 1]);
+            if (l != 1) gemm_dx_hip(n, K, N, dedx, net->weights[l], net->layer_dedy[l - 1], g_hip_dx_waves[l]);
             gemm_dw_hip(n, K, N, prev_y, dedx, net->layer_ydedx[l]);
         } else {
             if (l != 1) gemm_dx(n, K, N, dedx, net->weights[l], net->layer_dedy[l - 1]); /* :430 */

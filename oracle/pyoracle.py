@@ -55,6 +55,7 @@ def lib(variant="strict"):
         L.ora_set_num_threads.argtypes = [C.c_int]
         L.ora_set_gemm_split.argtypes = [C.c_int]
         L.ora_set_gemm_order.argtypes = [C.c_int, C.c_int]
+        L.ora_set_gemm_plan.argtypes = [C.c_int, C.c_int, C.c_int]
         if "OMP_NUM_THREADS" not in os.environ:
             # a container often sees all host CPUs but may only use a share of them: more threads than
             # that share makes every OpenMP region slower, not faster
@@ -223,13 +224,17 @@ def set_gemm_split(s, variant="strict"):
     lib(variant).ora_set_gemm_split(int(s))
 
 
-def set_gemm_order(order, s_out=1, variant="strict"):
+def set_gemm_order(order, s_out=1, variant="strict", plan=None):
     """MFMA-order twin (process-wide for that library): order "hip" / 1 = the HIP kernels' own summation order with
     fused multiply-adds -- forward / dX reductions over the 4 waves' contiguous ranges, the output layer over `s_out`
     slabs x 4 waves (the engine's choice: BPGpu.out_slabs()), dW over the frames in order; "ref" / 0 = the documented
     orders every parity test compares against.  With order "hip" the GEMMs of the HIP path equal this CPU model bit for
-    bit (tests/test_gpu_mfma_order.py), which leaves libm (expf, powf) as the only difference between the two."""
+    bit (tests/test_gpu_mfma_order.py), which leaves libm (expf, powf) as the only difference between the two.
+    plan: [(fwd_waves, dx_waves)] per layer 1..L-1 (BPGpu.gemm_plan()): 4 = reduction over the 4 waves of a 32 x 32-tile
+    workgroup (default), 1 = the 64 x 64-tile kernels' single chain per output element."""
     lib(variant).ora_set_gemm_order(1 if order in (1, "hip") else 0, int(s_out))
+    for l, (fw, dx) in enumerate(plan or [], start=1):  # BPGpu.gemm_plan(): which GEMM kernel each layer takes
+        lib(variant).ora_set_gemm_plan(l, int(fw), int(dx))
 
 
 def gamma(x):

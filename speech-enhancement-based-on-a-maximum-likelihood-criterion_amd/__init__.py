@@ -48,7 +48,7 @@ EXPORTS = [
     "mlggd_debug_stamp_select", "mlggd_debug_stamp_read",
     "mlggd_load_frames", "mlggd_train_frames", "mlggd_train_frames_async", "mlggd_cv_all_frames", "mlggd_forward_frames",
     "mlggd_alloc_pinned", "mlggd_alloc_pinned_on", "mlggd_free_pinned", "mlggd_set_cv_device_reduce",
-    "mlggd_comm_info", "mlggd_debug_plan_count", "mlggd_debug_math", "mlggd_debug_out_slabs",
+    "mlggd_comm_info", "mlggd_debug_plan_count", "mlggd_debug_math", "mlggd_debug_out_slabs", "mlggd_debug_gemm_plan",
 ]
 
 _lib = None
@@ -56,7 +56,7 @@ _lib = None
 
 def build(force=False):
     """Compile libmlggd.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(_CSRC, f) for f in ("engine.hip", "kernels.hip.h")]
+    srcs = [os.path.join(_CSRC, f) for f in ("engine.hip", "kernels.hip.h", "kernels64.hip.h")]
     srcs.append(os.path.join(_HERE, "..", "include", "mlggd.h"))
     stale = not os.path.exists(LIB_PATH) or any(
         os.path.getmtime(LIB_PATH) < os.path.getmtime(s) for s in srcs)
@@ -111,6 +111,7 @@ def load():
     L.mlggd_comm_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.mlggd_debug_plan_count.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     L.mlggd_debug_out_slabs.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    L.mlggd_debug_gemm_plan.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.mlggd_debug_math.argtypes = [C.c_void_p, C.c_char_p, _fp, C.c_float, _fp, C.c_size_t]
     L.mlggd_debug_stamp_select.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     L.mlggd_debug_stamp_read.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.c_int, C.POINTER(C.c_int)]
@@ -408,6 +409,16 @@ class BPGpu:
         n = C.c_int(0)
         _check(load().mlggd_debug_out_slabs(self._h, C.byref(n)))
         return n.value
+
+    def gemm_plan(self):
+        """[(fwd_waves, dx_waves)] per layer 1..L-1: 4 = the 32 x 32-tile kernels (reduction over 4 waves), 1 = the
+        64 x 64-tile kernels (one chain per output element)"""
+        out = []
+        for l in range(1, len(self.layersizes)):
+            f, d = C.c_int(0), C.c_int(0)
+            _check(load().mlggd_debug_gemm_plan(self._h, l, C.byref(f), C.byref(d)))
+            out.append((f.value, d.value))
+        return out
 
     def comm_info(self):
         """(ranks, rank) of the engine's RCCL communicator as RCCL reports them; (0, -1) without one."""

@@ -214,6 +214,9 @@ struct mlggd_engine {
     int fwd_pipe = 4, dx_pipe = 4;  // main loops software-pipelined inside the wave (forward: operands by LDS-DMA; 1: through staging registers; 0: the round-1 loops, for A/B)
     // 4 waves per workgroup (one per SIMD) since the main loops are pipelined inside the wave: a wave no longer needs a
     // partner on its SIMD to fill its chunk-boundary gaps, and four partial tiles reduce faster than eight
+    // 64 x 64-tile forward / dX kernels (kernels64.hip.h): 1 = where the shape gives every CU such a tile (units and
+    // frames multiples of 64, tiles >= CUs), 0 = never, 2 = wherever the shape divides (tests, A/B); MLGGD_TILE64
+    int tile64 = 1, n_cus = 256;
     int fwd_nw = 4, dx_nw = 4, dw_tile = 1, dw_persist = 1, dwp_per_cu = 2, dw_merge = 1, loss_fuse = 1, tile_map = 0, stage_ahead = 1;  // dw_tile 0 = auto
 
     // data parallel
@@ -496,6 +499,21 @@ static float *in_bunch_other(mlggd_engine *e) {
     return e->in_bunch == e->in_bunch_buf[0] ? e->in_bunch_buf[1] : e->in_bunch_buf[0];
 }
 
+// Which GEMM form a layer takes.  fwd: layer l's forward (output tile over units of l x frames); dx: the dX launched for
+// layer l (output tile over units of l-1 x frames).  The 64 x 64 form needs a whole number of such tiles and -- unless
+// forced -- at least one per CU; the output layer always takes the slab form (small N: K split over workgroups).
+static bool tile64_ok(const mlggd_engine *e, int units_p) {
+    if (e->tile64 == 0 || units_p % 64 != 0 || e->Bp % 64 != 0) return false;
+    return e->tile64 == 2 || (long)(units_p / 64) * (e->Bp / 64) >= e->n_cus;
+}
+static bool fwd64_used(const mlggd_engine *e, int l) {
+    if (e->fwd_pipe != 4 || e->fwd_nw != 4 || !tile64_ok(e, e->lsp[l])) return false;
+    return l != e->L - 1 || e->S_out == 1;  // an output layer only when it needs no split-K slabs (it is that wide)
+}
+static bool dx64_used(const mlggd_engine *e, int l) {
+    return l >= 2 && e->dx_pipe == 4 && e->dx_nw == 4 && tile64_ok(e, e->lsp[l - 1]);
+}
+
 static int run_transpose(mlggd_engine *e, const Bunch &bn, int frames) {
     ProfScope ps(e, KC_TRANSPOSE, 0);
     hipLaunchKernelGGL(k_transpose_in, dim3(stage_blocks(e)), dim3(256), 0, e->stream,
@@ -570,7 +588,19 @@ static int run_forward(mlggd_engine *e, const Bunch &bn, int frames, bool traini
                 gather_arm(e);
             ProfScope ps(e, KC_FWD, l);
             FwdArgs fa = fwd_args(e, l, e->Y[l]);
-            if (l != e->L - 1) {
+            if (fwd64_used(e, l)) {
+                fa.n_tiles = Np / 64;
+                fa.b_tiles = e->Bp / 64;
+                fa.b_shift = log2_or_minus1(fa.b_tiles);
+                const size_t lds = t64_lds_floats() * sizeof(float);
+                if (l != e->L - 1) {
+                    CHK(ensure_lds(e, k_fwd64<FWD_SIGMOID>, lds));
+                    launch_timed(e, k_fwd64<FWD_SIGMOID>, dim3(fa.n_tiles * fa.b_tiles), dim3(256), lds, e->stream, fa);
+                } else {
+                    CHK(ensure_lds(e, k_fwd64<FWD_SLAB>, lds));
+                    launch_timed(e, k_fwd64<FWD_SLAB>, dim3(fa.n_tiles * fa.b_tiles), dim3(256), lds, e->stream, fa);
+                }
+            } else if (l != e->L - 1) {
                 long long *st = stamps_for(e, KC_FWD, l, n_tiles * b_tiles);
 #define LAUNCH_FWD(NW, PIPE)                                                                                \
     {                                                                                                       \
@@ -1095,6 +1125,15 @@ static int run_dx(mlggd_engine *e, int l) {
     ProfScope ps(e, KC_DX, l);
     long long *st = stamps_for(e, KC_DX, l, (Kp / 32) * b_tiles);
     DxArgs xa = dx_args(e, l);
+    if (dx64_used(e, l)) {
+        xa.k_tiles = Kp / 64;
+        xa.b_tiles = e->Bp / 64;
+        xa.b_shift = log2_or_minus1(xa.b_tiles);
+        const size_t lds = t64_lds_floats() * sizeof(float);
+        CHK(ensure_lds(e, k_dx64, lds));
+        launch_timed(e, k_dx64, dim3(xa.k_tiles * xa.b_tiles), dim3(256), lds, e->stream, xa);
+        return launch_check("k_dx64");
+    }
 #define LAUNCH_DX(NW, PIPE)                                                                                  \
     {                                                                                                        \
         const size_t lds = dx_lds_floats<NW, PIPE>() * sizeof(float);                                        \
@@ -1490,10 +1529,15 @@ int mlggd_create(const mlggd_config *cfg, const float *const *weights, const flo
     if (const char *v = getenv("MLGGD_TILE_MAP")) e->tile_map = atoi(v);
     if (const char *v = getenv("MLGGD_STAGE_AHEAD")) e->stage_ahead = atoi(v);
     if (const char *v = getenv("MLGGD_CV_DEVICE")) e->cv_device = atoi(v) ? 1 : 0;
+    if (const char *v = getenv("MLGGD_TILE64")) e->tile64 = atoi(v);
     *out = e;  // so the caller can destroy on failure
 
     roctx_load();
     HIPCHK(hipSetDevice(e->device));
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) == hipSuccess && cus > 0) e->n_cus = cus;
+    }
     HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     // (the second compute stream only exists when MLGGD_TWO_STREAMS asks for it: every HIP stream takes one of the
     // process's few hardware queues, and two streams of one engine that land on the SAME queue serialise -- round 3:
@@ -2316,6 +2360,13 @@ int mlggd_comm_info(mlggd_handle e, int *nranks, int *rank) {
 int mlggd_debug_plan_count(mlggd_handle e, int *plans) {
     if (!e || !plans) return fail(MLGGD_ERR_ARG, "NULL argument");
     *plans = (int)e->dwp_tables.size();
+    return MLGGD_OK;
+}
+int mlggd_debug_gemm_plan(mlggd_handle e, int layer, int *fwd_waves, int *dx_waves) {
+    if (!e || !fwd_waves || !dx_waves) return fail(MLGGD_ERR_ARG, "NULL argument");
+    if (layer < 1 || layer >= e->L) return fail(MLGGD_ERR_ARG, "layer %d not in 1..%d", layer, e->L - 1);
+    *fwd_waves = fwd64_used(e, layer) ? 1 : e->fwd_nw;  // (the output layer's 4 waves x out_slabs otherwise)
+    *dx_waves = dx64_used(e, layer) ? 1 : e->dx_nw;
     return MLGGD_OK;
 }
 int mlggd_debug_out_slabs(mlggd_handle e, int *slabs) {

@@ -1549,6 +1549,7 @@ template <int NW, int PIPE = 1>
 __global__ __launch_bounds__(64 * NW) void k_dx(DxArgs A, long long *stamps) {
     dx_body<NW, PIPE>(A, (int)blockIdx.x, g_dyn_lds, stamps);
 }
+#include "kernels64.hip.h"  // k_fwd64 / k_dx64: the 64 x 64-tile forms for large minibatches
 template <int H, bool FUSED, bool POW2>
 __global__ __launch_bounds__(256) void k_dwp(const DwpDesc *__restrict__ table, int total, DwpConst C, long long *stamps) {
     dwp_body<H, FUSED, POW2>(table, total, C, (int)blockIdx.x, (int)gridDim.x, g_dyn_lds, stamps);

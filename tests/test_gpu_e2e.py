@@ -608,11 +608,19 @@ def test_bench_rehearses_the_data_parallel_path_on_one_gpu():
     d = json.loads(lines[0])
     assert "rehearsal" in d and d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and "incomplete" not in d
     assert d["config"]["dp_mode"] == "gather" and d["roofline"]["launches_timed"] == 64   # one dW launch per step (grouped exchange)
-    assert set(d["dp_arms"]) == {"allreduce", "gather", "shard", "gather_other_granularity"}
-    assert d["dp_arms"]["gather"]["same_as"] == "headline"
-    for arm in ("allreduce", "shard", "gather_other_granularity"):
+    assert list(d["dp_arms"]) == ["allreduce", "gather", "shard", "gather_other_granularity", "headline_mode_without_mainline",
+                                  "allreduce_unsharded_update"]
+    assert d["dp_arms"]["gather"]["same_as"] == "headline" and d["skipped"] == []        # everything fits the default budget
+    for arm in ("allreduce", "shard", "gather_other_granularity", "headline_mode_without_mainline", "allreduce_unsharded_update"):
         a = d["dp_arms"][arm]
         assert a["value"] > 1e5 and a["dp_breakdown"]["compute_us_by_class"]["dw"] > 0, (arm, a)
+    # the all-reduce arm updates the rank's block only (here the whole matrix: one rank) in one pass per layer
     assert d["dp_arms"]["allreduce"]["dp_breakdown"]["compute_us_by_class"]["update"] > 0   # k_apply_update ran
     assert d["ml_ggd"]["value"] > 1e5 and d["ml_ggd"]["dp_breakdown"]["compute_us_by_class"]["loss"] > 0
+    assert d["ml_ggd"]["stat_comm"]["value"] > 1e5                                        # ncclCommSplit worked
     assert d["value"] > 1e5 and 0 < d["ms_per_step"] < 5
+    # the parity leg of a multi-rank line (here world = 1): HIP through the communicator vs the oracle at bunchsize world x B
+    for leg in (d["loss_vs_oracle"], d["ml_ggd"]["loss_vs_oracle"]):
+        assert leg["replicas_identical"] is True and leg["steps"] == 5 and leg["oracle_bunchsize"] == 128
+        assert leg["cv_sqerr_rel"] < 1e-4 and leg["cv_abserr_rel"] < 1e-4 and leg["weights_relmax"] < 2e-5
+    assert d["ml_ggd"]["loss_vs_oracle"]["cv_loglik_rel"] < 1e-4

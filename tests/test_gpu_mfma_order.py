@@ -31,7 +31,7 @@ def ulp_report(name, a, b):
 
 
 def twin_net(pyoracle, eng, *args):
-    pyoracle.set_gemm_order("hip", eng.out_slabs())
+    pyoracle.set_gemm_order("hip", eng.out_slabs(), plan=eng.gemm_plan())
     return pyoracle.OracleNet(*args)
 
 
@@ -145,4 +145,107 @@ def test_one_real_step_differs_from_the_twin_only_through_libm(pkg, pyoracle, sy
     finally:
         pyoracle.set_gemm_order("ref")
         ref.close()
+        eng.close()
+
+
+@pytest.mark.parametrize("K,D,B", [(2048, 2048, 64), (2827, 192, 128), (96, 64, 256)])
+def test_the_64x64_tile_forward_equals_the_twin_bitwise(pkg, pyoracle, monkeypatch, K, D, B):
+    """k_fwd64 (csrc/kernels64.hip.h): one chain per output element over k ascending.  Read back through an output layer
+    wide enough for that tiling (MLGGD_TILE64=2 forces the form wherever the shape divides; one slab, so `out` is the
+    kernel's sum + bias): bit-identical to the twin with waves = 1 -- on ordinary data, K not a multiple of 128 included
+    (2827 -> 89 chunks: the remainder bodies of the 4-chunk ring)."""
+    monkeypatch.setenv("MLGGD_TILE64", "2")
+    monkeypatch.setenv("MLGGD_S_OUT", "1")
+    rng = np.random.default_rng(K + D + B)
+    W = rng.normal(0, 0.05, (K, D)).astype(np.float32)
+    b = rng.normal(0, 0.1, D).astype(np.float32)
+    x = rng.normal(0, 1, (B, K)).astype(np.float32)
+    t = rng.normal(0, 1, (B, D)).astype(np.float32)
+    eng = pkg.BPGpu(1, 0, [K, D], B, *HP, [W], [b], 2.0, 0)
+    assert eng.gemm_plan() == [(1, 4)] and eng.out_slabs() == 1          # the 64 x 64 form is what runs
+    try:
+        ora = twin_net(pyoracle, eng, [K, D], B, *HP, 2.0, 0, [W], [b])
+        assert eng.train(x, t) == 1 and ora.train(x, t) == 1
+        bad = ulp_report("out (k_fwd64)", eng.debug_tensor("out"), ora.tensor("out", rows=B))
+        bad += ulp_report("delta_w", eng.debug_tensor("delta_w", 1), ora.tensor("delta_w", 1))
+        pyoracle.set_gemm_order("hip", 1)                                # the 4-wave order is a different one
+        four = pyoracle.OracleNet([K, D], B, *HP, 2.0, 0, [W], [b])
+        four.train(x, t)
+        differs = not np.array_equal(four.tensor("out", rows=B), ora.tensor("out", rows=B))
+        four.close()
+        ora.close()
+    finally:
+        pyoracle.set_gemm_order("ref")
+        eng.close()
+    assert bad == 0 and differs
+
+
+@pytest.mark.parametrize("H,D,B", [(128, 2048, 64), (64, 257, 128), (192, 1000, 64)])
+def test_the_64x64_tile_dx_equals_the_twin_bitwise(pkg, pyoracle, monkeypatch, H, D, B):
+    """k_dx64: one chain per output element over the reduction index in quads ({4j, 4j+2} then {4j+1, 4j+3}); pad columns
+    (257 -> 288, 1000 -> 1024) and a chunk count that is not a multiple of 4 (288 / 32 = 9) included."""
+    monkeypatch.setenv("MLGGD_TILE64", "2")
+    K0 = 64
+    rng = np.random.default_rng(H + D + 1)
+    W1, b1 = np.zeros((K0, H), np.float32), np.zeros(H, np.float32)      # y_1 = 0.5 exactly on both sides
+    W2 = rng.normal(0, 0.05, (H, D)).astype(np.float32)
+    b2 = rng.normal(0, 0.1, D).astype(np.float32)
+    x = rng.normal(0, 1, (B, K0)).astype(np.float32)
+    t = rng.normal(0, 1, (B, D)).astype(np.float32)
+    eng = pkg.BPGpu(1, 0, [K0, H, D], B, *HP, [W1, W2], [b1, b2], 2.0, 0)
+    assert eng.gemm_plan()[1][1] == 1 and eng.gemm_plan()[0][0] == 1    # dX of layer 2 and the forward of layer 1: 64 x 64 form
+    try:
+        ora = twin_net(pyoracle, eng, [K0, H, D], B, *HP, 2.0, 0, [W1, W2], [b1, b2])
+        assert eng.train(x, t) == 1 and ora.train(x, t) == 1
+        assert np.all(eng.debug_tensor("y", 1) == 0.5) and np.all(ora.tensor("y", 1, rows=B) == 0.5)
+        bad = ulp_report("out", eng.debug_tensor("out"), ora.tensor("out", rows=B))
+        bad += ulp_report("dEdX_1 (k_dx64 over %d units)" % D, eng.debug_tensor("dedx", 1), ora.tensor("dedx", 1, rows=B))
+        bad += ulp_report("delta_w_1", eng.debug_tensor("delta_w", 1), ora.tensor("delta_w", 1))
+        bad += ulp_report("delta_w_2", eng.debug_tensor("delta_w", 2), ora.tensor("delta_w", 2))
+        ora.close()
+    finally:
+        pyoracle.set_gemm_order("ref")
+        eng.close()
+    assert bad == 0
+
+
+def test_hidden_layers_through_the_64x64_tile_kernels_match_the_oracle(pkg, pyoracle, synth, monkeypatch):
+    """Three sigmoid layers, ML-GGD, every hidden forward and dX through k_fwd64 / k_dx64 (forced at a small shape), two
+    steps against the documented-order oracle at the usual tolerances, both activation layouts checked, and against the
+    twin: activations within the sigmoid's 2 ulp of it after the first layer."""
+    monkeypatch.setenv("MLGGD_TILE64", "2")
+    ls, B = [40 * 5, 192, 128, 64, 40], 128
+    ws, bs = synth.make_weights(ls, seed=21)
+    rng = np.random.default_rng(22)
+    bs = [rng.uniform(-0.1, 0.1, b.shape).astype(np.float32) for b in bs]
+    inp, targ = synth.make_frames(2 * B, 40, 5, seed=23)
+    eng = pkg.BPGpu(1, 0, ls, B, *HP, ws, bs, 1.2, 1)
+    assert eng.gemm_plan() == [(1, 4), (1, 1), (1, 1), (4, 1)]
+    ora = pyoracle.OracleNet(ls, B, *HP, 1.2, 1, ws, bs)
+    try:
+        twin = twin_net(pyoracle, eng, ls, B, *HP, 1.2, 1, ws, bs)
+        assert eng.train(inp[:B], targ[:B]) == 1 and twin.train(inp[:B], targ[:B]) == 1
+        pyoracle.set_gemm_order("ref")
+        assert ora.train(inp[:B], targ[:B]) == 1
+        y1 = eng.debug_tensor("y", 1)
+        d = np.abs(y1.view(np.int32).astype(np.int64) - twin.tensor("y", 1, rows=B).view(np.int32).astype(np.int64))
+        assert d.max() <= 2, d.max()
+        assert eng.train(inp[B:], targ[B:]) == 1 and ora.train(inp[B:], targ[B:]) == 1
+        for l in (1, 2, 3):   # the two layouts every epilogue writes hold the same bits
+            assert np.array_equal(eng.debug_tensor("y", l), eng.debug_tensor("yt", l)), l
+            assert np.array_equal(eng.debug_tensor("dedx", l), eng.debug_tensor("dedxt", l)), l
+        we, be = eng.returnWeights()
+        wo, bo = ora.get_weights()
+        for l in range(4):
+            assert float(np.abs(we[l] - wo[l]).max() / np.abs(wo[l]).max()) < 2e-5, l
+            assert float(np.abs(be[l] - bo[l]).max() / np.abs(bo[l]).max()) < 2e-5, l
+            for name in ("dedx", "y"):
+                if name == "y" and l == 3:
+                    continue
+                a, r = eng.debug_tensor(name, l + 1), ora.tensor(name, l + 1, rows=B)
+                assert float(np.abs(a - r).max() / np.abs(r).max()) < 2e-4, (name, l)
+        twin.close()
+    finally:
+        pyoracle.set_gemm_order("ref")
+        ora.close()
         eng.close()
