@@ -766,13 +766,13 @@ def rank_main(args):
                 chk.train_resident(0, m * B)
                 done += m
             r = scores(chk, ml_, True)
-            s_out = chk.out_slabs() if hasattr(chk, "out_slabs") else 1
+            s_out = (chk.out_slabs(), chk.gemm_plan()) if hasattr(chk, "out_slabs") else (1, None)
             chk.close()
             return r, s_out
 
-        def oracle_after(ml_, beta_, n_, split=1, order="ref", s_out=1, variant="strict"):
+        def oracle_after(ml_, beta_, n_, split=1, order="ref", s_out=(1, None), variant="strict"):
             pyoracle.set_gemm_split(split, variant)
-            pyoracle.set_gemm_order(order, s_out, variant)
+            pyoracle.set_gemm_order(order, s_out[0], variant, plan=s_out[1])  # the engine's slabs and per-layer GEMM kernels
             try:
                 o = pyoracle.OracleNet(ls, B, 0.1, 0.9, 1e-5, beta_, ml_, ws, bs, variant=variant)
                 o.train_bunch(inp[:B], targ[:B])
@@ -797,6 +797,8 @@ def rank_main(args):
             yard = {}
             for name, kw in (("split4", {"split": 4}), ("split7", {"split": 7}), ("fma_build", {"variant": "fma"}),
                              ("mfma_order", {"order": "hip", "s_out": s_out})):
+                if not ml_ and name in ("split7", "fma_build"):
+                    continue  # MMSE is smooth (every twin sits at 1e-7): two yardsticks say it, four cost 50 s of CPU
                 if time.time() - T0 + (n_ + 2) * step_s * 1.2 > args.budget_s:
                     skipped.append({"leg": "yardstick %s (ml %d beta %.1f)" % (name, ml_, beta_), "elapsed_s": round(time.time() - T0, 1),
                                     "budget_s": args.budget_s})

@@ -1421,7 +1421,9 @@ static int run_step(mlggd_engine *e, int sample0, bool prestaged = false, const 
             // the blocks of all its ranks one after the other (they are disjoint: the union is the whole update).
             const int r_lo = !e->ar_shard ? 0 : e->fake_world ? 0 : e->rank;
             const int r_hi = !e->ar_shard ? 0 : e->fake_world ? e->world - 1 : e->rank;
+            const char *only = e->fake_world ? getenv("MLGGD_FAKE_ONLY_RANK") : nullptr;  // timing: one rank's share only (tools/dp_sim.py)
             for (int r = r_lo; r <= r_hi; r++) {
+                if (only && e->ar_shard && atoi(only) != r) continue;
                 const int row0 = e->ar_shard ? r * e->shard_rows[l] * 64 : 0;
                 const int row1 = e->ar_shard ? (row0 + e->shard_rows[l] * 64 < Kp ? row0 + e->shard_rows[l] * 64 : Kp) : Kp;
                 if (row1 <= row0) continue;  // a block that lies entirely in the pad rows
