@@ -9,7 +9,7 @@ for d in sys.argv[1:]:
             a = acc[row["Kernel_Name"].split("(")[0]][row["Counter_Name"]]
             a[0] += float(row["Counter_Value"]); a[1] += 1
 for k in sorted(acc):
-    if not ("k_dwp" in k or "k_fwd<0" in k or "k_dx" in k):
+    if not ("k_dwp" in k or "k_fwd<0" in k or "k_dx" in k or "k_fwd64" in k):
         continue
     print(k)
     for c in sorted(acc[k]):
