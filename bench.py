@@ -90,6 +90,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-ml", action="store_true", help="skip the ml_ggd (configs[2]) measurement")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--ramp", type=int, default=512,
+                    help="untimed clock-ramp steps before the headline's warm-up (profiler passes over slow shapes lower it)")
     ap.add_argument("--budget-s", type=float, default=240.0,
                     help="seconds from process start within which optional legs may still be STARTED (module docstring)")
     ap.add_argument("--dry-launch", action="store_true",
@@ -454,7 +456,7 @@ def rank_main(args):
     t_leg = time.time()
     eng = make_engine(ml, beta, args.dp_mode)
     mode = eng.dp_mode()
-    head = measure(eng, "headline", 512)
+    head = measure(eng, "headline", args.ramp)
     cost["measure"] = time.time() - t_leg
 
     roofline = None
