@@ -30,6 +30,101 @@ static_assert(4 * T64_SCR <= T64_NB * T64_CH, "the epilogue scratch aliases the 
 #define T64_LDSP(p) ((__attribute__((address_space(3))) void *)(p))
 
 // ---------------------------------------------------------------------------------------
+// The main loop the forward and the weight-gradient kernel share: C[64 x 64] += A^T B over `nch` chunks of 32 reduction
+// rows, both operands row-major with the reduction index as the ROW ([32][64] pieces: forward: W[k][n], Yt[k][b];
+// dW: Y[b][k], dEdX[b][n]).  4 waves as 2 x 2 (wm: half of A's columns, wn: half of B's); ring of 4 chunks, DMA three
+// chunks ahead, one barrier per chunk in the middle of its MFMA block.
+// after_prologue(): called once between the DMAs of chunks 0..2 and the first wait; it may issue EXTRA (template) more
+// vector-memory loads per lane (the dW kernel's W / delta tiles): vmcnt counts in issue order, so bodies 0 and 1 -- whose
+// awaited chunks 1, 2 are OLDER than those loads -- leave them in flight, and from body 2 on they have arrived.
+// nch >= 4.
+// ---------------------------------------------------------------------------------------
+template <int EXTRA, class F>
+__device__ __forceinline__ void t64_rowmajor_loop(const rsrc_t rA, const rsrc_t rB, const int voA, const int voB,
+                                                  const int rowA_bytes, const int rowB_bytes, const int endA, const int endB,
+                                                  const int nch, float *smem, const int wave, const int wm, const int wn,
+                                                  const int fo, f32x16 &acc, F after_prologue) {
+    float fa[16], fb[16], ga[16], gb[16];
+    // instruction Q (0..3) of this wave's share of chunk C: rows 4t..4t+3 of A (Q < 2) or of B (Q >= 2), t = 2 wave + (Q & 1)
+#define T64_DMA(C, BUF, Q)                                                                         \
+    {                                                                                              \
+        const int c_ = (C), t_ = 2 * wave + ((Q) & 1);                                             \
+        const bool live_ = c_ < nch;                                                               \
+        float *dst_ = smem + (BUF) * T64_CH + t_ * 256;                                            \
+        if ((Q) < 2)                                                                               \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, T64_LDSP(dst_), 16, voA,                  \
+                                                     live_ ? (32 * c_ + 4 * t_) * rowA_bytes : endA, 0, 0); \
+        else                                                                                       \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, T64_LDSP(dst_ + 2048), 16, voB,           \
+                                                     live_ ? (32 * c_ + 4 * t_) * rowB_bytes : endB, 0, 0); \
+    }
+#define T64_RD4(BUF, NA, NB, Q)                                                                    \
+    {                                                                                              \
+        const float *b_ = smem + (BUF) * T64_CH + fo;                                              \
+        _Pragma("unroll") for (int u = 4 * (Q); u < 4 * (Q) + 4; u++) {                           \
+            NA[u] = b_[u * 128 + 32 * wm];                                                         \
+            NB[u] = b_[2048 + u * 128 + 32 * wn];                                                  \
+        }                                                                                          \
+    }
+    // chunk C on (FA, FB), read from buffer CUR one body ago; chunk C+1 is in (or landing in) buffer CUR+1; chunk C+3
+    // goes to buffer CUR+3 = CUR-1, whose chunk C-1 every wave has finished reading (it passed the barrier of body C-1
+    // after the lgkmcnt wait at the top of that body).  VM: vector-memory operations that may still be in flight at the
+    // wait: the 8 DMAs of chunks C+2, C+3 (+ EXTRA in bodies 0 and 1).
+#define T64_BODY(FA, FB, NA, NB, CUR, C, VM)                                                       \
+    {                                                                                              \
+        __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0): the fragments of chunk C have arrived */ \
+        _Pragma("unroll") for (int g = 0; g < 4; g++) {                                            \
+            acc = mfma32(FA[2 * g], FB[2 * g], acc);                                               \
+            acc = mfma32(FA[2 * g + 1], FB[2 * g + 1], acc);                                       \
+            T64_DMA((C) + 3, ((CUR) + 3) & 3, g);                                                  \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
+        }                                                                                          \
+        __builtin_amdgcn_s_waitcnt(0x0F70 | ((VM) & 15) | (((VM) >> 4) << 14)); /* vmcnt(VM): this wave's part of chunk C+1 has landed */ \
+        __builtin_amdgcn_s_barrier();            /* ... and so has everybody else's */             \
+        _Pragma("unroll") for (int g = 4; g < 8; g++) {                                            \
+            acc = mfma32(FA[2 * g], FB[2 * g], acc);                                               \
+            acc = mfma32(FA[2 * g + 1], FB[2 * g + 1], acc);                                       \
+            T64_RD4(((CUR) + 1) & 3, NA, NB, g - 4);                                               \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
+        }                                                                                          \
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) T64_DMA(0, 0, q);
+#pragma unroll
+    for (int q = 0; q < 4; q++) T64_DMA(1, 1, q);
+#pragma unroll
+    for (int q = 0; q < 4; q++) T64_DMA(2, 2, q);
+    after_prologue();
+    __builtin_amdgcn_s_waitcnt(0x0F70 | ((8 + EXTRA) & 15) | (((8 + EXTRA) >> 4) << 14));
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int q = 0; q < 4; q++) T64_RD4(0, fa, fb, q);
+    __builtin_amdgcn_sched_barrier(0);
+    T64_BODY(fa, fb, ga, gb, 0, 0, 8 + EXTRA);
+    T64_BODY(ga, gb, fa, fb, 1, 1, 8 + EXTRA);
+    T64_BODY(fa, fb, ga, gb, 2, 2, 8);
+    T64_BODY(ga, gb, fa, fb, 3, 3, 8);
+    int c = 4;
+    for (; c + 4 <= nch; c += 4) {
+        T64_BODY(fa, fb, ga, gb, 0, c, 8);
+        T64_BODY(ga, gb, fa, fb, 1, c + 1, 8);
+        T64_BODY(fa, fb, ga, gb, 2, c + 2, 8);
+        T64_BODY(ga, gb, fa, fb, 3, c + 3, 8);
+    }
+    if (c < nch) {  // 1..3 chunks left: wave-uniform branches BETWEEN bodies only
+        T64_BODY(fa, fb, ga, gb, 0, c, 8);
+        if (c + 1 < nch) {
+            T64_BODY(ga, gb, fa, fb, 1, c + 1, 8);
+            if (c + 2 < nch) T64_BODY(fa, fb, ga, gb, 2, c + 2, 8);
+        }
+    }
+#undef T64_DMA
+#undef T64_RD4
+#undef T64_BODY
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // nothing may still be landing in LDS (the out-of-range chunks past the last)
+}
+
+// ---------------------------------------------------------------------------------------
 // Forward + bias + sigmoid (hidden layers):  X^T[n][b] = sum_k W[k][n] Yt_in[k][b] + bias[n];  y = 1/(1+expf(-x))
 // replaces kernMultiCopy + cublasSgemm(N,N) + kernSigmoid (BP_GPU.cu:360-364).  A.n_tiles = Np/64, A.b_tiles = Bp/64.
 // MODE FWD_SLAB: an output layer wide enough for this tiling (one slab: the raw sums go to slab[0][n][b]; the loss
@@ -65,78 +160,7 @@ __device__ __forceinline__ void fwd64_body(const FwdArgs &A, const int bid, floa
     for (int q = 0; q < 4; q++) bias_pre[q] = MODE == FWD_SIGMOID ? bias[n0 + 32 * wm + er + 8 * q] : 0.0f;
     asm volatile("" ::: "memory");
 
-    float fa[16], fb[16], ga[16], gb[16];
-    // instruction Q (0..3) of this wave's share of chunk C: rows 4t..4t+3 of W (Q < 2) or of Yt (Q >= 2), t = 2 wave + (Q & 1)
-#define F64_DMA(C, BUF, Q)                                                                         \
-    {                                                                                              \
-        const int c_ = (C), t_ = 2 * wave + ((Q) & 1);                                             \
-        const bool live_ = c_ < nch;                                                               \
-        float *dst_ = smem + (BUF) * T64_CH + t_ * 256;                                            \
-        if ((Q) < 2)                                                                               \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, T64_LDSP(dst_), 16, voW,                  \
-                                                     live_ ? (32 * c_ + 4 * t_) * Np * 4 : endW, 0, 0); \
-        else                                                                                       \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rY, T64_LDSP(dst_ + 2048), 16, voY,           \
-                                                     live_ ? (32 * c_ + 4 * t_) * Bp * 4 : endY, 0, 0); \
-    }
-#define F64_RD4(BUF, NA, NB, Q)                                                                    \
-    {                                                                                              \
-        const float *b_ = smem + (BUF) * T64_CH + fo;                                              \
-        _Pragma("unroll") for (int u = 4 * (Q); u < 4 * (Q) + 4; u++) {                           \
-            NA[u] = b_[u * 128 + 32 * wm];                                                         \
-            NB[u] = b_[2048 + u * 128 + 32 * wn];                                                  \
-        }                                                                                          \
-    }
-    // chunk C on (FA, FB), read from buffer CUR one body ago; chunk C+1 is in (or landing in) buffer CUR+1; chunk C+3
-    // goes to buffer CUR+3 = CUR-1, whose chunk C-1 every wave has finished reading (it passed the barrier of body C-1
-    // after the lgkmcnt wait at the top of that body)
-#define F64_BODY(FA, FB, NA, NB, CUR, C)                                                           \
-    {                                                                                              \
-        __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0): the fragments of chunk C have arrived */ \
-        _Pragma("unroll") for (int g = 0; g < 4; g++) {                                            \
-            acc = mfma32(FA[2 * g], FB[2 * g], acc);                                               \
-            acc = mfma32(FA[2 * g + 1], FB[2 * g + 1], acc);                                       \
-            F64_DMA((C) + 3, ((CUR) + 3) & 3, g);                                                  \
-            __builtin_amdgcn_sched_barrier(0);                                                     \
-        }                                                                                          \
-        __builtin_amdgcn_s_waitcnt(0x0F70 | 8); /* vmcnt(8): this wave's part of chunk C+1 has landed (C+2, C+3 may fly) */ \
-        __builtin_amdgcn_s_barrier();            /* ... and so has everybody else's */             \
-        _Pragma("unroll") for (int g = 4; g < 8; g++) {                                            \
-            acc = mfma32(FA[2 * g], FB[2 * g], acc);                                               \
-            acc = mfma32(FA[2 * g + 1], FB[2 * g + 1], acc);                                       \
-            F64_RD4(((CUR) + 1) & 3, NA, NB, g - 4);                                               \
-            __builtin_amdgcn_sched_barrier(0);                                                     \
-        }                                                                                          \
-    }
-#pragma unroll
-    for (int q = 0; q < 4; q++) F64_DMA(0, 0, q);
-#pragma unroll
-    for (int q = 0; q < 4; q++) F64_DMA(1, 1, q);
-#pragma unroll
-    for (int q = 0; q < 4; q++) F64_DMA(2, 2, q);
-    __builtin_amdgcn_s_waitcnt(0x0F70 | 8);
-    __builtin_amdgcn_s_barrier();
-#pragma unroll
-    for (int q = 0; q < 4; q++) F64_RD4(0, fa, fb, q);
-    __builtin_amdgcn_sched_barrier(0);
-    int c = 0;
-    for (; c + 4 <= nch; c += 4) {
-        F64_BODY(fa, fb, ga, gb, 0, c);
-        F64_BODY(ga, gb, fa, fb, 1, c + 1);
-        F64_BODY(fa, fb, ga, gb, 2, c + 2);
-        F64_BODY(ga, gb, fa, fb, 3, c + 3);
-    }
-    if (c < nch) {  // 1..3 chunks left (Kp = 32 mod 128): wave-uniform branches BETWEEN bodies only
-        F64_BODY(fa, fb, ga, gb, 0, c);
-        if (c + 1 < nch) {
-            F64_BODY(ga, gb, fa, fb, 1, c + 1);
-            if (c + 2 < nch) F64_BODY(fa, fb, ga, gb, 2, c + 2);
-        }
-    }
-#undef F64_DMA
-#undef F64_RD4
-#undef F64_BODY
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // nothing may still be landing in LDS (the out-of-range chunks past the last)
+    t64_rowmajor_loop<0>(rW, rY, voW, voY, Np * 4, Bp * 4, endW, endY, nch, smem, wave, wm, wn, fo, acc, [] {});
     __syncthreads();                     // every wave is done with the operand ring: the scratch below aliases it
 
     // epilogue, wave-private: accumulators -> S[n][b] -> bias + sigmoid, 16-byte stores of Yt [unit][frame]; the same
@@ -326,6 +350,111 @@ __device__ __forceinline__ void dx64_body(const DxArgs &A, const int bid, float 
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Weight gradient with the SGD update as its epilogue, for minibatches of >= 256 frames:
+//   G[k][n] = sum_b Y[b][k] dEdX[b][n];  delta = mom delta - lr (G / n_frames + wc W);  W = delta + 1.0f W
+// replaces cublasSgemm(N,T) + kernUpdatedelta x2 + kernAccSumrow + kernAccSum x2 (BP_GPU.cu:432-437), all layers in
+// one launch -- what k_dwp does at B = 128, where the kernel is HBM-bound and the W / delta stream of the NEXT tile has
+// to ride inside the current tile's MFMA block.  From 4 units of 64 frames on the kernel is MFMA-bound (>= 32 FLOP per
+// byte of W / delta traffic against a ridge of 19.7) and k_dwp's per-unit hand-off (vmcnt wait + barrier + the first
+// fragment reads of the next unit, with nothing to run beside them) is what costs: 85 % MFMA-pipe occupancy at 512
+// frames against 94 % for k_fwd64 (profiles/r04_sq_counters_cfg5.txt).  So: ONE 64 x 64 tile per workgroup, the
+// forward kernel's main loop over the frames (t64_rowmajor_loop: ring of 4 chunks of 32 frames, DMA three chunks ahead),
+// the tile's W / delta loaded into registers behind the prologue DMAs (consumed a whole main loop later), two
+// workgroups per CU so that one tile's epilogue (LDS transposition, update, stores) runs beside the other's MFMAs.
+// Tiles come from the same host-built table of 64-byte records as k_dwp's (engine.hip dwp_table): same tile order, same
+// chain per weight over the frames in order -> bit-identical to k_dwp (tests/test_gpu_e2e.py).
+// The bias gradient of the tiles of weight-row block 0 (kernAccSumrow order: frames added sequentially) is read from
+// dEdX in global memory after the main loop: 1 tile in 64 (k = 4096) takes ~2 us longer.
+// FUSED = false: G (and the bias gradient) are written instead (data-parallel all-reduce arm).
+// ---------------------------------------------------------------------------------------
+template <bool FUSED, bool POW2>
+__device__ __forceinline__ void dw64_body(const DwpDesc *__restrict__ table, const int total, const DwpConst C, const int bid,
+                                          float *smem) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
+    const int i = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
+    if (bid >= total) return;
+    const rsrc_t rT = make_rsrc(table, (size_t)total * sizeof(DwpDesc));
+    const DwpDesc tc = dwp_decode(__builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rT, 16 * (lane & 3), bid * 64, 0)));
+    const int rows = (int)(tc.packed & 0xFFu), colsw = (int)((tc.packed >> 8) & 0xFFu), nbias = (int)((tc.packed >> 16) & 0xFFu);
+    const float nf = C.nf, mom = C.mom, lr = C.lr, wc = C.wc, inv_nf = 1.0f / nf;
+    const int nch = (C.B + 31) >> 5;  // chunks of 32 frames; rows past B are zero pads of both operands
+    const rsrc_t rA = make_rsrc(tc.A, 0x7FFFFFFFu), rB = make_rsrc(tc.Bm, 0x7FFFFFFFu);
+    const rsrc_t rW = make_rsrc(tc.W, tc.szW), rD = make_rsrc(tc.D, FUSED ? tc.szW : 0);
+    const int r4 = lane >> 4, q16 = lane & 15;
+    const int voA = (r4 * tc.ldA + 4 * q16) * 4, voB = (r4 * tc.Np + 4 * q16) * 4;
+    const int fo = h * 64 + i;
+    constexpr int OOB = 0x7FFFFF00;
+    const int er = lane >> 3, ec = lane & 7;
+    int woff[4];  // this lane's float4 number q of the wave tile; out of range (load 0, store dropped) past the matrix
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        woff[q] = ((32 * wm + er + 8 * q) < rows && (32 * wn + 4 * ec) < colsw) ? ((32 * wm + er + 8 * q) * tc.Np + 32 * wn + 4 * ec) * 4 : OOB;
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+    float4 pw[4], pd[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) pw[q] = pd[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    t64_rowmajor_loop<FUSED ? 8 : 0>(rA, rB, voA, voB, tc.ldA * 4, tc.Np * 4, 0x7FFFFF00, 0x7FFFFF00, nch, smem, wave, wm, wn, fo, acc, [&] {
+        if (FUSED) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) pw[q] = bload4(rW, woff[q], 0);
+#pragma unroll
+            for (int q = 0; q < 4; q++) pd[q] = bload4(rD, woff[q], 0);
+        }
+    });
+    __syncthreads();  // every wave is done with the operand ring: the scratch below aliases it
+
+    float *S = smem + wave * T64_SCR;
+#pragma unroll
+    for (int r = 0; r < 16; r++) S[acc_row(r, lane) * 32 + i] = acc[r];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const float4 g = *reinterpret_cast<const float4 *>(&S[(er + 8 * q) * 32 + 4 * ec]);
+        if (FUSED) {  // kernUpdatedelta (DevFunc.cu:502) then kernAccSum (DevFunc.cu:440); G / n is a multiply when n is a power of two
+            const float4 w = pw[q];
+            float4 d = pd[q];
+            d.x = mom * d.x - lr * ((POW2 ? g.x * inv_nf : g.x / nf) + wc * w.x);
+            d.y = mom * d.y - lr * ((POW2 ? g.y * inv_nf : g.y / nf) + wc * w.y);
+            d.z = mom * d.z - lr * ((POW2 ? g.z * inv_nf : g.z / nf) + wc * w.z);
+            d.w = mom * d.w - lr * ((POW2 ? g.w * inv_nf : g.w / nf) + wc * w.w);
+            bstore4(d, rD, woff[q]);
+            bstore4(make_float4(d.x + 1.0f * w.x, d.y + 1.0f * w.y, d.z + 1.0f * w.z, d.w + 1.0f * w.w), rW, woff[q]);
+        } else {
+            bstore4(g, rW, woff[q]);
+        }
+    }
+    if (tid < nbias) {  // kernAccSumrow (DevFunc.cu:267-285 <- BP_GPU.cu:434): frames added sequentially; then the bias update (:435,437)
+        const int B = C.B;
+        float s = bload(rB, tid * 4, 0);
+        int b = 1;
+        for (; b + 16 <= B; b += 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) v[u] = bload(rB, tid * 4, (b + u) * tc.Np * 4);
+#pragma unroll
+            for (int u = 0; u < 16; u++) s += v[u];
+        }
+        for (; b < B; b++) s += bload(rB, tid * 4, b * tc.Np * 4);
+        const rsrc_t rb_ = make_rsrc(tc.bias, 256), rdb_ = make_rsrc(tc.dbias, FUSED ? 256 : 0);
+        if (FUSED) {
+            const float bv = bload(rb_, tid * 4, 0);
+            const float d = mom * bload(rdb_, tid * 4, 0) - lr * ((POW2 ? s * inv_nf : s / nf) + 0.0f * bv);
+            bstore1(d, rdb_, tid * 4);
+            bstore1(d + 1.0f * bv, rb_, tid * 4);
+        } else {
+            bstore1(s, rb_, tid * 4);
+        }
+    }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void k_fwd64(FwdArgs A) { fwd64_body<MODE>(A, (int)blockIdx.x, g_dyn_lds); }
 __global__ __launch_bounds__(256, 2) void k_dx64(DxArgs A) { dx64_body(A, (int)blockIdx.x, g_dyn_lds); }
+template <bool FUSED, bool POW2>
+__global__ __launch_bounds__(256, 2) void k_dw64(const DwpDesc *__restrict__ table, int total, DwpConst C) {
+    dw64_body<FUSED, POW2>(table, total, C, (int)blockIdx.x, g_dyn_lds);
+}
