@@ -37,7 +37,8 @@ static_assert(4 * T64_SCR <= T64_NB * T64_CH, "the epilogue scratch aliases the 
 // after_prologue(): called once between the DMAs of chunks 0..2 and the first wait; it may issue EXTRA (template) more
 // vector-memory loads per lane (the dW kernel's W / delta tiles): vmcnt counts in issue order, so bodies 0 and 1 -- whose
 // awaited chunks 1, 2 are OLDER than those loads -- leave them in flight, and from body 2 on they have arrived.
-// nch >= 4.
+// endA / endB: a byte offset at or past the end of the resource's range -- where the chunks past the last one are
+// "loaded" from (out of range for every lane: no memory request).
 // ---------------------------------------------------------------------------------------
 template <int EXTRA, class F>
 __device__ __forceinline__ void t64_rowmajor_loop(const rsrc_t rA, const rsrc_t rB, const int voA, const int voB,
@@ -100,22 +101,29 @@ __device__ __forceinline__ void t64_rowmajor_loop(const rsrc_t rA, const rsrc_t 
 #pragma unroll
     for (int q = 0; q < 4; q++) T64_RD4(0, fa, fb, q);
     __builtin_amdgcn_sched_barrier(0);
+    // (wave-uniform branches BETWEEN bodies only: a body is one basic block)
     T64_BODY(fa, fb, ga, gb, 0, 0, 8 + EXTRA);
-    T64_BODY(ga, gb, fa, fb, 1, 1, 8 + EXTRA);
-    T64_BODY(fa, fb, ga, gb, 2, 2, 8);
-    T64_BODY(ga, gb, fa, fb, 3, 3, 8);
-    int c = 4;
-    for (; c + 4 <= nch; c += 4) {
-        T64_BODY(fa, fb, ga, gb, 0, c, 8);
-        T64_BODY(ga, gb, fa, fb, 1, c + 1, 8);
-        T64_BODY(fa, fb, ga, gb, 2, c + 2, 8);
-        T64_BODY(ga, gb, fa, fb, 3, c + 3, 8);
-    }
-    if (c < nch) {  // 1..3 chunks left: wave-uniform branches BETWEEN bodies only
-        T64_BODY(fa, fb, ga, gb, 0, c, 8);
-        if (c + 1 < nch) {
-            T64_BODY(ga, gb, fa, fb, 1, c + 1, 8);
-            if (c + 2 < nch) T64_BODY(fa, fb, ga, gb, 2, c + 2, 8);
+    if (nch > 1) {
+        T64_BODY(ga, gb, fa, fb, 1, 1, 8 + EXTRA);
+        if (nch > 2) {
+            T64_BODY(fa, fb, ga, gb, 2, 2, 8);
+            if (nch > 3) {
+                T64_BODY(ga, gb, fa, fb, 3, 3, 8);
+                int c = 4;
+                for (; c + 4 <= nch; c += 4) {
+                    T64_BODY(fa, fb, ga, gb, 0, c, 8);
+                    T64_BODY(ga, gb, fa, fb, 1, c + 1, 8);
+                    T64_BODY(fa, fb, ga, gb, 2, c + 2, 8);
+                    T64_BODY(ga, gb, fa, fb, 3, c + 3, 8);
+                }
+                if (c < nch) {  // 1..3 chunks left
+                    T64_BODY(fa, fb, ga, gb, 0, c, 8);
+                    if (c + 1 < nch) {
+                        T64_BODY(ga, gb, fa, fb, 1, c + 1, 8);
+                        if (c + 2 < nch) T64_BODY(fa, fb, ga, gb, 2, c + 2, 8);
+                    }
+                }
+            }
         }
     }
 #undef T64_DMA
@@ -379,7 +387,10 @@ __device__ __forceinline__ void dw64_body(const DwpDesc *__restrict__ table, con
     const int rows = (int)(tc.packed & 0xFFu), colsw = (int)((tc.packed >> 8) & 0xFFu), nbias = (int)((tc.packed >> 16) & 0xFFu);
     const float nf = C.nf, mom = C.mom, lr = C.lr, wc = C.wc, inv_nf = 1.0f / nf;
     const int nch = (C.B + 31) >> 5;  // chunks of 32 frames; rows past B are zero pads of both operands
-    const rsrc_t rA = make_rsrc(tc.A, 0x7FFFFFFFu), rB = make_rsrc(tc.Bm, 0x7FFFFFFFu);
+    // operand ranges end with the last chunk's last row (reads never leave the allocation + its slack: dwp_table), so
+    // that range itself is an out-of-range offset for EVERY lane (an offset short of the range's end is a real access)
+    const int rangeA = 32 * nch * tc.ldA * 4, rangeB = 32 * nch * tc.Np * 4;
+    const rsrc_t rA = make_rsrc(tc.A, (size_t)rangeA), rB = make_rsrc(tc.Bm, (size_t)rangeB);
     const rsrc_t rW = make_rsrc(tc.W, tc.szW), rD = make_rsrc(tc.D, FUSED ? tc.szW : 0);
     const int r4 = lane >> 4, q16 = lane & 15;
     const int voA = (r4 * tc.ldA + 4 * q16) * 4, voB = (r4 * tc.Np + 4 * q16) * 4;
@@ -397,7 +408,7 @@ __device__ __forceinline__ void dw64_body(const DwpDesc *__restrict__ table, con
     float4 pw[4], pd[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) pw[q] = pd[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-    t64_rowmajor_loop<FUSED ? 8 : 0>(rA, rB, voA, voB, tc.ldA * 4, tc.Np * 4, 0x7FFFFF00, 0x7FFFFF00, nch, smem, wave, wm, wn, fo, acc, [&] {
+    t64_rowmajor_loop<FUSED ? 8 : 0>(rA, rB, voA, voB, tc.ldA * 4, tc.Np * 4, rangeA, rangeB, nch, smem, wave, wm, wn, fo, acc, [&] {
         if (FUSED) {
 #pragma unroll
             for (int q = 0; q < 4; q++) pw[q] = bload4(rW, woff[q], 0);
