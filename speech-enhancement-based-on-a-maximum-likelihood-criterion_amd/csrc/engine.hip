@@ -217,9 +217,6 @@ struct mlggd_engine {
     // 64 x 64-tile forward / dX kernels (kernels64.hip.h): 1 = where the shape gives every CU such a tile (units and
     // frames multiples of 64, tiles >= CUs), 0 = never, 2 = wherever the shape divides (tests, A/B); MLGGD_TILE64
     int tile64 = 1, n_cus = 256;
-    // one-tile-per-workgroup dW + update kernel (k_dw64): 1 = from 4 units of 64 frames on (MFMA-bound: 256+ frames),
-    // 0 = never (k_dwp everywhere), 2 = from 2 units on (tests, A/B); MLGGD_DW64
-    int dw64 = 1;
     int fwd_nw = 4, dx_nw = 4, dw_tile = 1, dw_persist = 1, dwp_per_cu = 2, dw_merge = 1, loss_fuse = 1, tile_map = 0, stage_ahead = 1;  // dw_tile 0 = auto
 
     // data parallel
@@ -809,26 +806,6 @@ static int launch_dwp_t(mlggd_engine *e, const DwpJobs &J, bool fused, hipStream
             hipLaunchKernelGGL((k_dwp_bias<H, false>), dim3(grid), dim3(256), lds, st, table, J.total, C, (long long *)nullptr);
         }
         return launch_check("k_dwp_bias");
-    }
-    if ((e->dw64 == 1 && H >= 4) || (e->dw64 == 2 && H >= 2)) {
-        // 256+ frames per tile: one tile per workgroup, the forward kernel's main loop over the frames (kernels64.hip.h)
-        const DwpDesc *t64 = nullptr;
-        CHK(dwp_table(e, J, fused, 0, &t64));
-        const size_t lds64 = t64_lds_floats() * sizeof(float);
-        unsigned nb64;
-        memcpy(&nb64, &C.nf, sizeof(nb64));
-        const bool p2 = (nb64 & 0x007FFFFFu) == 0u && C.nf >= 1.0f;
-#define DW64_LAUNCH(FUSED_, POW2_)                                                                        \
-    {                                                                                                     \
-        CHK(ensure_lds(e, k_dw64<FUSED_, POW2_>, lds64));                                                 \
-        launch_timed(e, k_dw64<FUSED_, POW2_>, dim3(J.total), dim3(256), lds64, st, t64, J.total, C);     \
-    }
-        if (fused && p2) DW64_LAUNCH(true, true)
-        else if (fused) DW64_LAUNCH(true, false)
-        else if (p2) DW64_LAUNCH(false, true)
-        else DW64_LAUNCH(false, false)
-#undef DW64_LAUNCH
-        return launch_check("k_dw64");
     }
     CHK(dwp_table(e, J, fused, grid, &table));
     if constexpr (H == 2 || H == 8) {
@@ -1556,7 +1533,6 @@ int mlggd_create(const mlggd_config *cfg, const float *const *weights, const flo
     if (const char *v = getenv("MLGGD_STAGE_AHEAD")) e->stage_ahead = atoi(v);
     if (const char *v = getenv("MLGGD_CV_DEVICE")) e->cv_device = atoi(v) ? 1 : 0;
     if (const char *v = getenv("MLGGD_TILE64")) e->tile64 = atoi(v);
-    if (const char *v = getenv("MLGGD_DW64")) e->dw64 = atoi(v);
     *out = e;  // so the caller can destroy on failure
 
     roctx_load();

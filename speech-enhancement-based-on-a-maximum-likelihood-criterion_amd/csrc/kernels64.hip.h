@@ -358,114 +358,6 @@ __device__ __forceinline__ void dx64_body(const DxArgs &A, const int bid, float 
     }
 }
 
-// ---------------------------------------------------------------------------------------
-// Weight gradient with the SGD update as its epilogue, for minibatches of >= 256 frames:
-//   G[k][n] = sum_b Y[b][k] dEdX[b][n];  delta = mom delta - lr (G / n_frames + wc W);  W = delta + 1.0f W
-// replaces cublasSgemm(N,T) + kernUpdatedelta x2 + kernAccSumrow + kernAccSum x2 (BP_GPU.cu:432-437), all layers in
-// one launch -- what k_dwp does at B = 128, where the kernel is HBM-bound and the W / delta stream of the NEXT tile has
-// to ride inside the current tile's MFMA block.  From 4 units of 64 frames on the kernel is MFMA-bound (>= 32 FLOP per
-// byte of W / delta traffic against a ridge of 19.7) and k_dwp's per-unit hand-off (vmcnt wait + barrier + the first
-// fragment reads of the next unit, with nothing to run beside them) is what costs: 85 % MFMA-pipe occupancy at 512
-// frames against 94 % for k_fwd64 (profiles/r04_sq_counters_cfg5.txt).  So: ONE 64 x 64 tile per workgroup, the
-// forward kernel's main loop over the frames (t64_rowmajor_loop: ring of 4 chunks of 32 frames, DMA three chunks ahead),
-// the tile's W / delta loaded into registers behind the prologue DMAs (consumed a whole main loop later), two
-// workgroups per CU so that one tile's epilogue (LDS transposition, update, stores) runs beside the other's MFMAs.
-// Tiles come from the same host-built table of 64-byte records as k_dwp's (engine.hip dwp_table): same tile order, same
-// chain per weight over the frames in order -> bit-identical to k_dwp (tests/test_gpu_e2e.py).
-// The bias gradient of the tiles of weight-row block 0 (kernAccSumrow order: frames added sequentially) is read from
-// dEdX in global memory after the main loop: 1 tile in 64 (k = 4096) takes ~2 us longer.
-// FUSED = false: G (and the bias gradient) are written instead (data-parallel all-reduce arm).
-// ---------------------------------------------------------------------------------------
-template <bool FUSED, bool POW2>
-__device__ __forceinline__ void dw64_body(const DwpDesc *__restrict__ table, const int total, const DwpConst C, const int bid,
-                                          float *smem) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
-    const int i = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
-    if (bid >= total) return;
-    const rsrc_t rT = make_rsrc(table, (size_t)total * sizeof(DwpDesc));
-    const DwpDesc tc = dwp_decode(__builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rT, 16 * (lane & 3), bid * 64, 0)));
-    const int rows = (int)(tc.packed & 0xFFu), colsw = (int)((tc.packed >> 8) & 0xFFu), nbias = (int)((tc.packed >> 16) & 0xFFu);
-    const float nf = C.nf, mom = C.mom, lr = C.lr, wc = C.wc, inv_nf = 1.0f / nf;
-    const int nch = (C.B + 31) >> 5;  // chunks of 32 frames; rows past B are zero pads of both operands
-    // operand ranges end with the last chunk's last row (reads never leave the allocation + its slack: dwp_table), so
-    // that range itself is an out-of-range offset for EVERY lane (an offset short of the range's end is a real access)
-    const int rangeA = 32 * nch * tc.ldA * 4, rangeB = 32 * nch * tc.Np * 4;
-    const rsrc_t rA = make_rsrc(tc.A, (size_t)rangeA), rB = make_rsrc(tc.Bm, (size_t)rangeB);
-    const rsrc_t rW = make_rsrc(tc.W, tc.szW), rD = make_rsrc(tc.D, FUSED ? tc.szW : 0);
-    const int r4 = lane >> 4, q16 = lane & 15;
-    const int voA = (r4 * tc.ldA + 4 * q16) * 4, voB = (r4 * tc.Np + 4 * q16) * 4;
-    const int fo = h * 64 + i;
-    constexpr int OOB = 0x7FFFFF00;
-    const int er = lane >> 3, ec = lane & 7;
-    int woff[4];  // this lane's float4 number q of the wave tile; out of range (load 0, store dropped) past the matrix
-#pragma unroll
-    for (int q = 0; q < 4; q++)
-        woff[q] = ((32 * wm + er + 8 * q) < rows && (32 * wn + 4 * ec) < colsw) ? ((32 * wm + er + 8 * q) * tc.Np + 32 * wn + 4 * ec) * 4 : OOB;
-
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; r++) acc[r] = 0.0f;
-    float4 pw[4], pd[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) pw[q] = pd[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-    t64_rowmajor_loop<FUSED ? 8 : 0>(rA, rB, voA, voB, tc.ldA * 4, tc.Np * 4, rangeA, rangeB, nch, smem, wave, wm, wn, fo, acc, [&] {
-        if (FUSED) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) pw[q] = bload4(rW, woff[q], 0);
-#pragma unroll
-            for (int q = 0; q < 4; q++) pd[q] = bload4(rD, woff[q], 0);
-        }
-    });
-    __syncthreads();  // every wave is done with the operand ring: the scratch below aliases it
-
-    float *S = smem + wave * T64_SCR;
-#pragma unroll
-    for (int r = 0; r < 16; r++) S[acc_row(r, lane) * 32 + i] = acc[r];
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const float4 g = *reinterpret_cast<const float4 *>(&S[(er + 8 * q) * 32 + 4 * ec]);
-        if (FUSED) {  // kernUpdatedelta (DevFunc.cu:502) then kernAccSum (DevFunc.cu:440); G / n is a multiply when n is a power of two
-            const float4 w = pw[q];
-            float4 d = pd[q];
-            d.x = mom * d.x - lr * ((POW2 ? g.x * inv_nf : g.x / nf) + wc * w.x);
-            d.y = mom * d.y - lr * ((POW2 ? g.y * inv_nf : g.y / nf) + wc * w.y);
-            d.z = mom * d.z - lr * ((POW2 ? g.z * inv_nf : g.z / nf) + wc * w.z);
-            d.w = mom * d.w - lr * ((POW2 ? g.w * inv_nf : g.w / nf) + wc * w.w);
-            bstore4(d, rD, woff[q]);
-            bstore4(make_float4(d.x + 1.0f * w.x, d.y + 1.0f * w.y, d.z + 1.0f * w.z, d.w + 1.0f * w.w), rW, woff[q]);
-        } else {
-            bstore4(g, rW, woff[q]);
-        }
-    }
-    if (tid < nbias) {  // kernAccSumrow (DevFunc.cu:267-285 <- BP_GPU.cu:434): frames added sequentially; then the bias update (:435,437)
-        const int B = C.B;
-        float s = bload(rB, tid * 4, 0);
-        int b = 1;
-        for (; b + 16 <= B; b += 16) {
-            float v[16];
-#pragma unroll
-            for (int u = 0; u < 16; u++) v[u] = bload(rB, tid * 4, (b + u) * tc.Np * 4);
-#pragma unroll
-            for (int u = 0; u < 16; u++) s += v[u];
-        }
-        for (; b < B; b++) s += bload(rB, tid * 4, b * tc.Np * 4);
-        const rsrc_t rb_ = make_rsrc(tc.bias, 256), rdb_ = make_rsrc(tc.dbias, FUSED ? 256 : 0);
-        if (FUSED) {
-            const float bv = bload(rb_, tid * 4, 0);
-            const float d = mom * bload(rdb_, tid * 4, 0) - lr * ((POW2 ? s * inv_nf : s / nf) + 0.0f * bv);
-            bstore1(d, rdb_, tid * 4);
-            bstore1(d + 1.0f * bv, rb_, tid * 4);
-        } else {
-            bstore1(s, rb_, tid * 4);
-        }
-    }
-}
-
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void k_fwd64(FwdArgs A) { fwd64_body<MODE>(A, (int)blockIdx.x, g_dyn_lds); }
 __global__ __launch_bounds__(256, 2) void k_dx64(DxArgs A) { dx64_body(A, (int)blockIdx.x, g_dyn_lds); }
-template <bool FUSED, bool POW2>
-__global__ __launch_bounds__(256, 2) void k_dw64(const DwpDesc *__restrict__ table, int total, DwpConst C) {
-    dw64_body<FUSED, POW2>(table, total, C, (int)blockIdx.x, g_dyn_lds);
-}
