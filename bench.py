@@ -805,7 +805,12 @@ def rank_main(args):
                     skipped.append({"leg": "yardstick %s (ml %d beta %.1f)" % (name, ml_, beta_), "elapsed_s": round(time.time() - T0, 1),
                                     "budget_s": args.budget_s})
                     continue
-                yard[name] = delta(oracle_after(ml_, beta_, n_, **kw), ref, ml_)
+                tw = oracle_after(ml_, beta_, n_, **kw)
+                yard[name] = delta(tw, ref, ml_)
+                if name == "mfma_order":
+                    # same summation order on both sides (the GEMMs are bit-identical, tests/test_gpu_mfma_order.py):
+                    # what separates the HIP path from THIS twin is libm alone (expf in the sigmoid, powf in the loss)
+                    leg["hip_vs_mfma_order_twin"] = delta(hip, tw, ml_)
             leg["oracle_twins_vs_oracle"] = yard
             if yard:
                 worst = {k: max(y[k] for y in yard.values()) for k in leg["loss_vs_oracle"]}
@@ -818,7 +823,8 @@ def rank_main(args):
         head_leg = parity_leg(ml, beta, n, ref=ref_head)
         out["loss_vs_oracle"] = dict(head_leg["loss_vs_oracle"], steps=head_leg["steps"])
         out["loss_vs_oracle_twins"] = {"oracle_twins_vs_oracle": head_leg["oracle_twins_vs_oracle"],
-                                       "hip_over_largest_twin": head_leg.get("hip_over_largest_twin")}
+                                       "hip_over_largest_twin": head_leg.get("hip_over_largest_twin"),
+                                       "hip_vs_mfma_order_twin": head_leg.get("hip_vs_mfma_order_twin")}
         if "ml_ggd" in out:
             n_ml = min(n, 150)
             for key, b_, what in (("ml_ggd", 1.2, None),
@@ -832,6 +838,7 @@ def rank_main(args):
                 tgt["loss_vs_oracle"] = dict(leg["loss_vs_oracle"], steps=leg["steps"])
                 tgt["oracle_twins_vs_oracle"] = leg["oracle_twins_vs_oracle"]
                 tgt["hip_over_largest_twin"] = leg.get("hip_over_largest_twin")
+                tgt["hip_vs_mfma_order_twin"] = leg.get("hip_vs_mfma_order_twin")  # libm only (same summation order)
     out["skipped"] = skipped
     out["elapsed_s"] = round(time.time() - T0, 1)
     wd.enter("teardown", 120, "ncclCommDestroy")
