@@ -63,8 +63,10 @@ HBM_PEAK_GBPS = 8000.0        # HBM3E peak (spec), same table
 
 DP_EXCHANGE = {0: None, 1: "all-reduce of weight gradients (RCCL)",
                2: "all-gather of the gradient factors Y, dEdX (RCCL); every rank forms the global gradient",
-               3: "all-gather of the gradient factors Y, dEdX; each rank updates its block of weight rows; all-gather of W"}
-DP_MODE_NAME = {0: None, 1: "allreduce", 2: "gather", 3: "shard"}
+               3: "all-gather of the gradient factors Y, dEdX; each rank updates its block of weight rows; all-gather of W",
+               4: "all-to-all of the activations Y (each rank receives only the units of its block of weight rows), all-gather of dEdX; "
+                  "each rank updates its block; all-gather of W"}
+DP_MODE_NAME = {0: None, 1: "allreduce", 2: "gather", 3: "shard", 4: "shard_a2a"}
 
 
 def flop_per_frame(ls):
@@ -83,7 +85,7 @@ def parse_args(argv=None):
     ap.add_argument("--bunch", type=int, default=128)
     ap.add_argument("--hidden", type=int, default=2048)
     ap.add_argument("--nhid", type=int, default=3)
-    ap.add_argument("--dp-mode", choices=["auto", "allreduce", "gather", "shard"], default="auto",
+    ap.add_argument("--dp-mode", choices=["auto", "allreduce", "gather", "shard", "shard_a2a"], default="auto",
                     help="gradient exchange of the headline number for N > 1 (auto: engine default, DESIGN.md section 6)")
     ap.add_argument("--no-dp-arms", action="store_true", help="N > 1: do not also measure the other exchange modes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -501,7 +503,8 @@ def rank_main(args):
                 units, "true" if mode != 1 else "false", "true" if n_glob & (n_glob - 1) == 0 else "false",
                 "all layers in one launch" if nl == 1 else "%d launches per step" % nl,
                 {0: "", 1: "", 2: ", over the %d gathered frames of all ranks" % (B * world),
-                 3: ", this rank's block of weight rows over the %d gathered frames of all ranks" % (B * world)}[mode])
+                 3: ", this rank's block of weight rows over the %d gathered frames of all ranks" % (B * world),
+                 4: ", this rank's block of weight rows over the %d frames of all ranks (activations by all-to-all)" % (B * world)}[mode])
             if fl / by < MFMA_F32_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBPS * 1e9):
                 roofline = {"bound": "hbm", "kernel": name, "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS,
                             "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": traffic}
@@ -652,6 +655,7 @@ def rank_main(args):
         # whose defaults rest on one-GPU rehearsals (MLGGD_DP_FINE, MLGGD_DP_MAINLINE, MLGGD_DP_AR_SHARD).
         fine_default = os.environ.get("MLGGD_DP_FINE")
         arm_specs = [("allreduce", "allreduce", None), ("gather", "gather", None), ("shard", "shard", None),
+                     ("shard_a2a", "shard_a2a", None),
                      ("gather_other_granularity", "gather", {"MLGGD_DP_FINE": "0" if fine_default == "1" else "1"}),
                      ("headline_mode_without_mainline", DP_MODE_NAME[mode], {"MLGGD_DP_MAINLINE": "0"}),
                      ("allreduce_unsharded_update", "allreduce", {"MLGGD_DP_AR_SHARD": "0"})]
@@ -698,14 +702,14 @@ def rank_main(args):
         reh = {"what": "this workload through a 1-rank RCCL communicator: the exchange path's fixed cost without links; "
                        "single-GPU step for comparison: ms_per_step above", "ms_per_step": {}}
         try:
-            for arm, env in (("allreduce", None), ("gather", None), ("shard", None),
+            for arm, env in (("allreduce", None), ("gather", None), ("shard", None), ("shard_a2a", None),
                              ("allreduce_unsharded_update", {"MLGGD_DP_AR_SHARD": "0"})):
                 if not fits("dp_rehearsal_1rank." + arm, est_arm):
                     continue
                 for k, v in (env or {}).items():
                     os.environ[k] = v
                 try:
-                    e2 = make_engine(ml, beta, arm.split("_")[0], comm=True)
+                    e2 = make_engine(ml, beta, "allreduce" if arm.startswith("allreduce") else arm, comm=True)
                 finally:
                     for k in (env or {}):
                         os.environ.pop(k, None)

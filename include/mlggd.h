@@ -185,14 +185,15 @@ int mlggd_kernel_work(mlggd_handle h, const char *kernel_class, int layer, doubl
 int mlggd_dw_launches_per_step(mlggd_handle h, int *launches);
 /* 0 = single device, 1 = data parallel by all-reduce of the weight gradients, 2 = by all-gather of their
  * factors with the update replicated on every rank, 3 = the same with the update sharded over the ranks and
- * W all-gathered (defaults: 2 up to 5 ranks, 3 from 6 ranks, 1 where the shape rules out the gather --
+ * W all-gathered, 4 = 3 with the activations exchanged by all-to-all, each rank receiving only the units of its block
+ * of weight rows (opt-in: MLGGD_DP_MODE=shard_a2a) (defaults: 2 up to 5 ranks, 3 from 6 ranks, 1 where the shape rules out the gather --
  * bunchsize % 32 != 0 or world*bunchsize not in {64,128,256,512,1024}; MLGGD_DP_MODE=allreduce|gather|shard
  * at comm init overrides) */
 int mlggd_dp_mode(mlggd_handle h, int *mode);
 /* Test hook: emulate `world_size` ranks on one GPU (device copies / adds instead of collectives).  Every
  * training step then consumes world_size*bunchsize rows of the resident chunk, emulated rank r owning rows
  * [r*bunchsize,(r+1)*bunchsize) of them.  mode: 0 = factor all-gather + replicated update, 1 = factor
- * all-gather + sharded update, 2 = gradient all-reduce. */
+ * all-gather + sharded update, 2 = gradient all-reduce, 3 = sharded update with the activations by all-to-all. */
 int mlggd_debug_fake_world(mlggd_handle h, int world_size, int mode);
 /* Test hook: number of launch plans (tile-record tables) the persistent dW kernel has cached; constant after the
  * first steps of a run (2 on one GPU, a few in the data-parallel modes). */

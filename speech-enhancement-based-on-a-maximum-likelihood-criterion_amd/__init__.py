@@ -399,7 +399,8 @@ class BPGpu:
         return n.value
 
     def dp_mode(self):
-        """0 single device, 1 all-reduce of gradients, 2 all-gather of the gradient factors, 3 = 2 + sharded update"""
+        """0 single device, 1 all-reduce of gradients, 2 all-gather of the gradient factors, 3 = 2 + sharded update,
+        4 = 3 with the activations exchanged by all-to-all (each rank receives only its block's units)"""
         n = C.c_int(0)
         _check(load().mlggd_dp_mode(self._h, C.byref(n)))
         return n.value
@@ -442,10 +443,10 @@ class BPGpu:
         """CV sums formed on the device (no n x D copy back) instead of the reference-order host loop."""
         _check(load().mlggd_set_cv_device_reduce(self._h, 1 if on else 0))
 
-    def fake_world(self, world_size, sharded=False, allreduce=False):
+    def fake_world(self, world_size, sharded=False, allreduce=False, a2a=False):
         """Emulate world_size ranks on this GPU: every step consumes world_size*bunchsize rows, rank r owns
         rows [r*bunchsize,(r+1)*bunchsize) of them (test hook, mlggd_debug_fake_world)."""
-        _check(load().mlggd_debug_fake_world(self._h, int(world_size), 2 if allreduce else 1 if sharded else 0))
+        _check(load().mlggd_debug_fake_world(self._h, int(world_size), 3 if a2a else 2 if allreduce else 1 if sharded else 0))
 
     def stamp_select(self, kernel_class, layer):
         _check(load().mlggd_debug_stamp_select(self._h, kernel_class.encode(), int(layer)))

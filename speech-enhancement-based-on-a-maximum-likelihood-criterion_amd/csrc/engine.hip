@@ -59,6 +59,8 @@ struct RcclApi {
     decltype(&ncclAllReduce) AllReduce_ = nullptr;
     decltype(&ncclAllGather) AllGather_ = nullptr;
     decltype(&ncclReduceScatter) ReduceScatter_ = nullptr;
+    decltype(&ncclSend) Send_ = nullptr;  // optional: the all-to-all form of the sharded update
+    decltype(&ncclRecv) Recv_ = nullptr;
     decltype(&ncclCommSplit) CommSplit = nullptr;        // optional: MLGGD_DP_STAT_COMM
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclGetErrorString) GetErrorString_ = nullptr;
@@ -96,6 +98,8 @@ static int rccl_load() {
     g_rccl.AllGather_ = (decltype(&ncclAllGather))dlsym(lib, "ncclAllGather");
     g_rccl.ReduceScatter_ = (decltype(&ncclReduceScatter))dlsym(lib, "ncclReduceScatter");
     g_rccl.CommSplit = (decltype(&ncclCommSplit))dlsym(lib, "ncclCommSplit");
+    g_rccl.Send_ = (decltype(&ncclSend))dlsym(lib, "ncclSend");
+    g_rccl.Recv_ = (decltype(&ncclRecv))dlsym(lib, "ncclRecv");
     g_rccl.CommDestroy = (decltype(&ncclCommDestroy))dlsym(lib, "ncclCommDestroy");
     g_rccl.GetErrorString_ = (decltype(&ncclGetErrorString))dlsym(lib, "ncclGetErrorString");
     g_rccl.GroupStart = (decltype(&ncclGroupStart))dlsym(lib, "ncclGroupStart");
@@ -225,6 +229,15 @@ struct mlggd_engine {
     // activations Y_{l-1} and dEdX_l of every rank; each rank then forms the global-minibatch gradient itself)
     int dp_mode = 0;  // 2 = gather + SHARDED update: each rank updates its block of weight rows, then W is all-gathered
     int shard_rows[MLGGD_MAXLAYER] = {0};  // 64-row tile rows of layer l owned by each rank
+    // Sharded update with the ACTIVATIONS exchanged by all-to-all (MLGGD_DP_MODE=shard_a2a; dp_mode stays 2): rank o
+    // forms the gradient of ITS block of weight rows of every layer, for which it needs every rank's Y_{l-1} only in
+    // the units of that block -- 1/world of what the all-gather of the whole Y_{l-1} delivers.  The producers write Y
+    // (and the staged input rows) blocked by owner (kernels.hip.h y_blocked_base), each block is one message, and
+    // what arrives is a plain [world x frames][block width] matrix.  dEdX_l is still all-gathered (every rank needs
+    // all of its units).  Per rank and step at 8 x 128 frames, 2827-2048^3-257: 4 + 23 MB of factors + 51 MB of W
+    // blocks = 78 MB instead of 106 -- the one built exchange whose link arithmetic fits the >= 6x target.
+    int dp_a2a = 0;
+    std::vector<float *> Ysrc[MLGGD_MAXLAYER];  // emulated world only: source rank s's blocked Y_l (all owners' blocks)
     hipEvent_t ev_W[MLGGD_MAXLAYER] = {0}, ev_dw_done = nullptr;
     bool ev_W_pending[MLGGD_MAXLAYER] = {false};
     bool fake_world = false;  // test hook: `world` ranks emulated one after the other on this GPU, no communicator
@@ -405,6 +418,7 @@ static FwdArgs fwd_args(mlggd_engine *e, int l, float *Yrow_out) {
     a.map = e->tile_map;
     a.b_shift = log2_or_minus1(a.b_tiles);
     a.s_shift = log2_or_minus1(a.S);
+    a.yblk = (e->dp_a2a && l < e->L - 1) ? e->shard_rows[l + 1] * 64 : 0;  // Y_l is layer l+1's K-side factor
     return a;
 }
 
@@ -491,6 +505,7 @@ static StageArgs stage_args(mlggd_engine *e, const Bunch &bn, int frames, float 
     a.first = bn.first;
     a.fdim = e->fdim;
     a.rows_out = rows_out;
+    a.yblk = e->dp_a2a ? e->shard_rows[1] * 64 : 0;  // the staged rows are layer 1's K-side factor
     return a;
 }
 static int stage_blocks(const mlggd_engine *e) { return (e->lsp[0] / 32) * (e->Bp / 32); }
@@ -550,6 +565,7 @@ static int gather_end(mlggd_engine *e);
 static void gather_arm(mlggd_engine *e);
 static int gather_begin_armed(mlggd_engine *e);
 static int gather_one(mlggd_engine *e, const float *src, float *dst, size_t count, hipStream_t st);
+static int exchange_y(mlggd_engine *e, int l, const float *src, hipStream_t st);
 enum { GATHER_INPUT = 1, GATHER_HIDDEN = 2, GATHER_HIDDEN_EACH = 4 };  // data-parallel factor exchange issued from inside the forward pass
 
 static int run_forward(mlggd_engine *e, const Bunch &bn, int frames, bool training, bool prestaged = false,
@@ -567,7 +583,7 @@ static int run_forward(mlggd_engine *e, const Bunch &bn, int frames, bool traini
         // the communication stream has already waited on an event recorded after that launch (sharded update: the W
         // gathers did), it needs no new event
         CHK(gather_begin(e, prestaged && e->comm_after_dw && e->dp_mainline));
-        CHK(gather_one(e, in_rows, e->Yall[0], (size_t)e->Bp * e->lsp[0], nullptr));
+        CHK(exchange_y(e, 0, in_rows, nullptr));
         CHK(gather_end(e));
     }
     e->comm_after_dw = false;
@@ -639,12 +655,12 @@ static int run_forward(mlggd_engine *e, const Bunch &bn, int frames, bool traini
         if (drop && l != e->L - 1) CHK(run_dropout(e, l, nullptr));
         if ((gather_flags & GATHER_HIDDEN_EACH) && l < e->L - 1) {  // each hidden layer's activations at once
             CHK(gather_begin_armed(e));
-            CHK(gather_one(e, e->Y[l], e->Yall[l], (size_t)e->Bp * e->lsp[l], nullptr));
+            CHK(exchange_y(e, l, e->Y[l], nullptr));
             CHK(gather_end(e));
         }
         if ((gather_flags & GATHER_HIDDEN) && l == e->L - 2) {  // all hidden activations exist: send them
             CHK(gather_begin_armed(e));                         // beside the output layer, the loss and dX
-            for (int g = 1; g < e->L - 1; g++) CHK(gather_one(e, e->Y[g], e->Yall[g], (size_t)e->Bp * e->lsp[g], nullptr));
+            for (int g = 1; g < e->L - 1; g++) CHK(exchange_y(e, g, e->Y[g], nullptr));
             CHK(gather_end(e));
         }
     }
@@ -707,7 +723,7 @@ static int dwp_table(mlggd_engine *e, const DwpJobs &J, bool fused, int grid, co
         a.Yrow = s.Yrow; a.dEdX = s.dEdX; a.Wt = s.Wt; a.delta = s.delta; a.G = s.G;
         a.bias = s.bias; a.dbias = s.dbias; a.gb = s.gb;
         a.ldA = s.ldA; a.K = s.K; a.N = s.N; a.Kp = s.Kp; a.Np = s.Np; a.n_wg = s.n_wg; a.ntiles = s.ntiles;
-        a.k_first = s.k_first; a.wd_off = s.wd_off; a.do_bias = s.do_bias;
+        a.k_first = s.k_first; a.wd_off = s.wd_off; a.do_bias = s.do_bias; a.k_base = s.k_base;
         key.tile_end[j] = J.tile_end[j];
     }
     key.njobs = J.njobs;
@@ -731,7 +747,7 @@ static int dwp_table(mlggd_engine *e, const DwpJobs &J, bool fused, int grid, co
             const int kt = a.k_first + tl / a.n_wg, nt = tl % a.n_wg;
             const int k0 = kt * 64, n0 = nt * 64;
             DwpDesc &d = recs[n];
-            d.A = a.Yrow + k0;
+            d.A = a.Yrow + (k0 - a.k_base);
             d.Bm = a.dEdX + n0;
             const size_t base = (size_t)k0 * a.Np + n0;
             int rows = a.K - k0;
@@ -883,11 +899,28 @@ static bool gather_usable(const mlggd_engine *e, int world) {
 }
 static int gather_alloc(mlggd_engine *e) {
     const size_t rows = (size_t)e->world * e->Bp;
-    CHK(dev_alloc(e, &e->Yall[0], rows * e->lsp[0]));
-    for (int l = 1; l < e->L; l++) {
-        if (l != e->L - 1) CHK(dev_alloc(e, &e->Yall[l], rows * e->lsp[l]));
-        CHK(dev_alloc(e, &e->dEdXall[l], rows * e->lsp[l]));
+    for (int l = 0; l < e->L - 1; l++) {
+        // all-to-all form: this rank's block of units from every rank ([world x Bp][block width]); shard_alloc ran first
+        const size_t width = e->dp_a2a ? (size_t)e->shard_rows[l + 1] * 64 : (size_t)e->lsp[l];
+        CHK(dev_alloc(e, &e->Yall[l], rows * width));
+        if (e->dp_a2a) {
+            // the producers write Y_l (l = 0: the staged rows, two buffers) blocked by owner: world blocks of [Bp][width]
+            if (l == 0) {
+                CHK(dev_alloc(e, &e->in_bunch_buf[0], rows * width));
+                CHK(dev_alloc(e, &e->in_bunch_buf[1], rows * width));
+                e->in_bunch = e->in_bunch_buf[0];
+            } else {
+                CHK(dev_alloc(e, &e->Y[l], rows * width));
+            }
+            if (e->fake_world)
+                for (int s = 0; s + 1 < e->world; s++) {
+                    float *q = nullptr;
+                    CHK(dev_alloc(e, &q, rows * width));
+                    e->Ysrc[l].push_back(q);
+                }
+        }
     }
+    for (int l = 1; l < e->L; l++) CHK(dev_alloc(e, &e->dEdXall[l], rows * e->lsp[l]));
     HIPCHK(hipEventCreateWithFlags(&e->ev_ready, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&e->ev_gathered, hipEventDisableTiming));
     for (int l = 1; l < e->L; l++) HIPCHK(hipEventCreateWithFlags(&e->ev_layer[l], hipEventDisableTiming));
@@ -916,6 +949,21 @@ static int gather_one(mlggd_engine *e, const float *src, float *dst, size_t coun
         return MLGGD_OK;
     }
     NCCLCHK(g_rccl.AllGather(src, dst, count, 7 /* ncclFloat32 */, e->comm, st));
+    return MLGGD_OK;
+}
+// The K-side factor of layer l+1 (Y_l; l = 0: the staged input rows) to the ranks that need it: every rank's rows to every
+// rank (all-gather), or -- all-to-all form of the sharded update -- block p of this rank's owner-blocked Y_l to rank p,
+// slot s of Yall[l] receiving rank s's block for THIS rank.  Called between gather_begin / gather_end, whose
+// ncclGroupStart / End make the send / recv pairs one collective.
+static int exchange_y(mlggd_engine *e, int l, const float *src, hipStream_t st = nullptr) {
+    if (!e->dp_a2a) return gather_one(e, src, e->Yall[l], (size_t)e->Bp * e->lsp[l], st);
+    if (e->fake_world) return MLGGD_OK;  // the emulation assembles Yall[l] per virtual owner from the sources' blocks (run_step)
+    if (!st) st = e->comm_stream;
+    const size_t cnt = (size_t)e->Bp * e->shard_rows[l + 1] * 64;
+    for (int p = 0; p < e->world; p++) {
+        NCCLCHK((int)g_rccl.Send_(src + (size_t)p * cnt, cnt, ncclFloat32, p, e->comm, st));
+        NCCLCHK((int)g_rccl.Recv_(e->Yall[l] + (size_t)p * cnt, cnt, ncclFloat32, p, e->comm, st));
+    }
     return MLGGD_OK;
 }
 // the communication stream picks up everything the main stream has produced so far (already_ordered: it has, through
@@ -997,6 +1045,10 @@ static DwpJobs dwp_jobs_shard(mlggd_engine *e, float nf, int r, int pass, bool o
             a.B = e->world * e->Bp;
             const int k_wg = a.ntiles / a.n_wg;
             const int kf = r * e->shard_rows[l];
+            if (e->dp_a2a) {  // Yall[l-1] holds the units of this rank's block only: [world x Bp][block width]
+                a.ldA = e->shard_rows[l] * 64;
+                a.k_base = pass == 0 ? kf * 64 : 0;
+            }
             const int kl = kf + e->shard_rows[l] < k_wg ? kf + e->shard_rows[l] : k_wg;
             if (pass == 0 && kl > kf) {
                 a.k_first = kf;
@@ -1199,11 +1251,16 @@ static int fake_world_prepass(mlggd_engine *e, int sample0, float nf, float inv_
                 HIPCHK(hipMemcpyAsync(dst + (size_t)r * count, src, count * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
                 return MLGGD_OK;
             };
-            CHK(put(in_rows, e->Yall[0], (size_t)Bp * e->lsp[0]));
-            for (int l = 1; l < L; l++) {
-                if (l != L - 1) CHK(put(e->Y[l], e->Yall[l], (size_t)Bp * e->lsp[l]));
-                CHK(put(e->dEdX[l], e->dEdXall[l], (size_t)Bp * e->lsp[l]));
+            if (e->dp_a2a) {  // keep source r's owner-blocked factors whole: every virtual owner picks its block later
+                for (int l = 0; l < L - 1; l++) {
+                    const size_t all = (size_t)e->world * Bp * e->shard_rows[l + 1] * 64;
+                    HIPCHK(hipMemcpyAsync(e->Ysrc[l][r], l == 0 ? in_rows : e->Y[l], all * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
+                }
+            } else {
+                CHK(put(in_rows, e->Yall[0], (size_t)Bp * e->lsp[0]));
+                for (int l = 1; l < L - 1; l++) CHK(put(e->Y[l], e->Yall[l], (size_t)Bp * e->lsp[l]));
             }
+            for (int l = 1; l < L; l++) CHK(put(e->dEdX[l], e->dEdXall[l], (size_t)Bp * e->lsp[l]));
         } else {
             for (int l = L - 1; l >= 1; l--) {
                 CHK(launch_dw_layer(e, l, in_rows, false, nf, e->stream));
@@ -1266,7 +1323,7 @@ static int run_step(mlggd_engine *e, int sample0, bool prestaged = false, const 
     RoctxRange back_range("backward: dX, dW + update, exchange");
     if (gather && ML == 1 && L > 2) {
         CHK(gather_begin(e));
-        for (int g = 1; g < L - 1; g++) CHK(gather_one(e, e->Y[g], e->Yall[g], (size_t)Bp * e->lsp[g]));
+        for (int g = 1; g < L - 1; g++) CHK(exchange_y(e, g, e->Y[g], nullptr));
         CHK(gather_end(e));
     }
     const bool two = e->two_streams != 0;
@@ -1345,6 +1402,15 @@ static int run_step(mlggd_engine *e, int sample0, bool prestaged = false, const 
             const char *only = getenv("MLGGD_FAKE_ONLY_RANK");  // timing: run one rank's share only (tools/dp_sim.py)
             for (int r = 0; r < e->world; r++) {
                 if (only && atoi(only) != r) continue;
+                if (e->dp_a2a)  // what the all-to-all delivers to virtual owner r: its block of every source's Y_l
+                    for (int l = 0; l < L - 1; l++) {
+                        const size_t cnt = (size_t)Bp * e->shard_rows[l + 1] * 64;
+                        for (int sr = 0; sr < e->world; sr++) {
+                            const float *src = sr + 1 < e->world ? e->Ysrc[l][sr] : (l == 0 ? in_rows : e->Y[l]);
+                            HIPCHK(hipMemcpyAsync(e->Yall[l] + (size_t)sr * cnt, src + (size_t)r * cnt, cnt * sizeof(float),
+                                                  hipMemcpyDeviceToDevice, dws));
+                        }
+                    }
                 if (only || r == e->world - 1) {  // the bias update comes from the LAST rank's bias-only tiles
                     DwpJobs Jb = dwp_jobs_shard(e, nf, r, 1, false);
                     if (Jb.total > 0) CHK(launch_dwp(e, Jb, true, dws, 1, units));
@@ -2157,6 +2223,15 @@ int mlggd_debug_tensor(mlggd_handle e, const char *name, int layer, float *dst, 
         std::vector<float> t((size_t)Np * Bp);
         HIPCHK(hipMemcpyAsync(t.data(), src, t.size() * 4, hipMemcpyDeviceToHost, e->stream));
         HIPCHK(hipStreamSynchronize(e->stream));
+        const int yb = (nm == "y" && e->dp_a2a && layer < L - 1) ? e->shard_rows[layer + 1] * 64 : 0;
+        if (yb) {  // owner-blocked layout (all-to-all form): [block][Bp][yb]
+            std::vector<float> tb((size_t)e->world * Bp * yb);
+            HIPCHK(hipMemcpyAsync(tb.data(), src, tb.size() * 4, hipMemcpyDeviceToHost, e->stream));
+            HIPCHK(hipStreamSynchronize(e->stream));
+            for (int b = 0; b < B; b++)
+                for (int n = 0; n < N; n++) dst[(size_t)b * N + n] = tb[(size_t)(n / yb) * Bp * yb + (size_t)b * yb + n % yb];
+            return MLGGD_OK;
+        }
         for (int b = 0; b < B; b++)
             for (int n = 0; n < N; n++)
                 dst[(size_t)b * N + n] = tr ? t[(size_t)n * Bp + b] : t[(size_t)b * Np + n];
@@ -2282,10 +2357,11 @@ int mlggd_comm_init(mlggd_handle e, const void *id, int world_size, int rank) {
         // update ~35 us per extra rank: DESIGN.md section 6 -- a cost model, not yet a measurement)
         mode = gather_usable(e, world_size) ? (world_size >= 6 ? 2 : 1) : 0;
         if (m && !strcmp(m, "allreduce")) mode = 0;
-        if (m && (!strcmp(m, "gather") || !strcmp(m, "shard"))) {
+        if (m && (!strcmp(m, "gather") || !strcmp(m, "shard") || !strcmp(m, "shard_a2a"))) {
             if (!gather_usable(e, world_size))
                 return fail(MLGGD_ERR_ARG, "MLGGD_DP_MODE=%s needs bunchsize %% 32 == 0 and world*bunchsize in {64,128,256,512,1024}", m);
-            mode = !strcmp(m, "shard") ? 2 : 1;
+            mode = !strcmp(m, "gather") ? 1 : 2;
+            e->dp_a2a = !strcmp(m, "shard_a2a") ? 1 : 0;  // opt-in only: no default or threshold changes before a scaling record exists
         }
     }
     CHK(rccl_load());
@@ -2303,9 +2379,11 @@ int mlggd_comm_init(mlggd_handle e, const void *id, int world_size, int rank) {
             NCCLCHK(g_rccl.CommSplit(e->comm, 0, rank, &e->stat_comm, nullptr));  // collective: every rank takes this branch (same env, same MLflag)
         }
     CHK(create_comm_stream(e));
+    if (e->dp_a2a && (!g_rccl.Send_ || !g_rccl.Recv_)) return fail(MLGGD_ERR_COMM, "MLGGD_DP_MODE=shard_a2a: librccl has no ncclSend / ncclRecv");
     if (e->dp_mode >= 1) {
+        if (e->dp_a2a) CHK(shard_alloc(e));  // the block table first: the all-to-all buffers are sized by it
         CHK(gather_alloc(e));
-        return e->dp_mode == 2 ? shard_alloc(e) : MLGGD_OK;
+        return (e->dp_mode == 2 && !e->dp_a2a) ? shard_alloc(e) : MLGGD_OK;
     }
     return allreduce_alloc(e);
 }
@@ -2320,7 +2398,7 @@ int mlggd_comm_init(mlggd_handle e, const void *id, int world_size, int rank) {
 int mlggd_debug_fake_world(mlggd_handle e, int world_size, int mode) {
     if (!e) return fail(MLGGD_ERR_ARG, "NULL handle");
     if (e->comm || e->fake_world) return fail(MLGGD_ERR_STATE, "communicator already initialised");
-    if (mode < 0 || mode > 2) return fail(MLGGD_ERR_ARG, "mode %d not in 0..2", mode);
+    if (mode < 0 || mode > 3) return fail(MLGGD_ERR_ARG, "mode %d not in 0..3", mode);
     if (world_size < 1 || (mode != 2 && !gather_usable(e, world_size)))
         return fail(MLGGD_ERR_ARG, "fake world of %d ranks: needs bunchsize %% 32 == 0 and world*bunchsize in {64,...,1024}", world_size);
     if (e->cfg.dropoutflag == 1 && world_size > 1)
@@ -2329,7 +2407,8 @@ int mlggd_debug_fake_world(mlggd_handle e, int world_size, int mode) {
     e->world = world_size;
     e->rank = world_size - 1;  // the rank that takes the real exchange path; the others are emulated before it
     e->fake_world = true;
-    e->dp_mode = mode == 2 ? 0 : mode == 1 ? 2 : 1;
+    e->dp_mode = mode == 2 ? 0 : (mode == 1 || mode == 3) ? 2 : 1;
+    e->dp_a2a = mode == 3 ? 1 : 0;
     dp_knobs(e);
     CHK(create_comm_stream(e));
     CHK(dev_alloc(e, &e->colsum_tot, e->Dp));
@@ -2340,6 +2419,7 @@ int mlggd_debug_fake_world(mlggd_handle e, int world_size, int mode) {
         HIPCHK(hipStreamSynchronize(e->stream));
         return MLGGD_OK;
     }
+    if (mode == 3) CHK(shard_alloc(e));
     CHK(gather_alloc(e));
     if (mode == 1) CHK(shard_alloc(e));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -2379,7 +2459,8 @@ int mlggd_debug_out_slabs(mlggd_handle e, int *slabs) {
 }
 int mlggd_dp_mode(mlggd_handle e, int *mode) {
     if (!e || !mode) return fail(MLGGD_ERR_ARG, "NULL argument");
-    *mode = (e->comm || e->fake_world) ? 1 + e->dp_mode : 0;  // 0 single device, 1 all-reduce, 2 gather, 3 gather + sharded update
+    // 0 single device, 1 all-reduce, 2 gather, 3 gather + sharded update, 4 = 3 with the activations by all-to-all
+    *mode = (e->comm || e->fake_world) ? (e->dp_a2a ? 4 : 1 + e->dp_mode) : 0;
     return MLGGD_OK;
 }
 

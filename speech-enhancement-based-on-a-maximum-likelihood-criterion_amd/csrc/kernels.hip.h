@@ -114,7 +114,18 @@ struct FwdArgs {
     float *Yt_out, *Y_out, *slab;
     int Kp, Np, Bp, N, n_tiles, b_tiles, S, map;
     int b_shift, s_shift;  // log2 of b_tiles / S when they are powers of two, else -1 (divmod_by)
+    int yblk;              // 0: Y_out is row-major [Bp][Np]; > 0: blocked by owner (y_blocked_base)
 };
+// The row-major activations Y [frame][unit] are what the dW kernels read -- and, data parallel, what a rank SENDS.  In
+// the all-to-all form of the sharded update rank o only needs the units of ITS block of weight
+// rows from every other rank, so the producer writes Y blocked by owner: [unit block o][frame][unit within the block]
+// (block width yblk, a multiple of 64, so a 32- or 64-wide output tile never straddles two blocks); each block is then
+// one contiguous message, and what arrives is a plain [world x frames][yblk] matrix for the dW tile records.
+// u0: first unit of the tile.  Returns the offset of (frame 0, unit u0); frames are yblk floats apart.
+__device__ __forceinline__ size_t y_blocked_base(int u0, int yblk, int Bp) {
+    const int blk = (int)((unsigned)u0 / (unsigned)yblk);
+    return (size_t)blk * Bp * yblk + (u0 - blk * yblk);
+}
 // LDS floats needed by fwd_body<.,NW>: staging/reduction tiles + the 32x33 transposition tile
 // staging / reduction tiles (two 8 KB tiles per wave in the LDS-DMA form, PIPE 4; one otherwise) + the 32x36 transposition tile
 template <int NW, int PIPE> constexpr int fwd_lds_floats() { return NW * (PIPE == 4 ? 4096 : 2048) + 32 * 36; }
@@ -436,8 +447,9 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &A, const int bid, float 
             tileT[col4 + 3][row] = y4.w;
             __syncthreads();
             // thread -> frame row, 4 consecutive units
-            *reinterpret_cast<float4 *>(&Y_out[(size_t)(b0 + row) * Np + n0 + col4]) =
-                *reinterpret_cast<const float4 *>(&tileT[row][col4]);
+            const size_t yo = A.yblk ? y_blocked_base(n0, A.yblk, Bp) + (size_t)(b0 + row) * A.yblk + col4
+                                     : (size_t)(b0 + row) * Np + n0 + col4;
+            *reinterpret_cast<float4 *>(&Y_out[yo]) = *reinterpret_cast<const float4 *>(&tileT[row][col4]);
         }
         stamp(stamps, 3, bid);
         stamp_clk(stamps, 6, bid);
@@ -479,7 +491,8 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &A, const int bid, float 
 #pragma unroll
         for (int q = 0; q < EPT; q++) {
             const int e = tid + NT * q, bl = e >> 5, nl = e & 31;
-            if (e < 1024) Y_out[(size_t)(b0 + bl) * Np + n0 + nl] = tileT[bl][nl];
+            if (e < 1024)
+                Y_out[A.yblk ? y_blocked_base(n0, A.yblk, Bp) + (size_t)(b0 + bl) * A.yblk + nl : (size_t)(b0 + bl) * Np + n0 + nl] = tileT[bl][nl];
         }
     }
     stamp(stamps, 3, bid);
@@ -1093,6 +1106,7 @@ struct DwpArgs {
     // row block 0 run on every rank so that every rank applies the same bias update); do_bias = 0
     // suppresses the bias update of a job that does own row block 0
     int k_first, wd_off, do_bias;
+    int k_base;  // first unit that Yrow's columns hold (0: all of them; all-to-all form: the rank's block starts here)
 };
 // One launch may walk the tiles of several layers (every dW(l) only needs dEdX_l and Y_{l-1}, both
 // final once the last dX has run): job j owns the global tile numbers [tile_end[j-1], tile_end[j]).
@@ -1682,6 +1696,7 @@ struct StageArgs {
     const int *first;
     int fdim;
     float *rows_out;
+    int yblk;  // 0: rows_out is row-major [Bp][Kp]; > 0: blocked by owner, [Kp / yblk blocks][Bp][yblk] (y_blocked_base)
 };
 // SUB: 256-thread staging tiles per workgroup (1: the workgroup is one tile; 4: a 1024-thread workgroup stages tiles
 // 4*bid .. 4*bid+3, of which the ones past n_tiles do nothing but keep the barrier company)
@@ -1707,7 +1722,10 @@ __device__ __forceinline__ void transpose_in_body(const StageArgs &A, const int 
                 const size_t base = first ? (size_t)first[b] * fdim : (size_t)b * ld;
                 v = in[base + k];
             }
-            if (rows_out) rows_out[(size_t)b * A.Kp + k] = v;  // b < Bp, k < Kp: the grid's tiles cover exactly that
+            if (rows_out) {  // b < Bp, k < Kp: the grid's tiles cover exactly that
+                if (A.yblk) rows_out[y_blocked_base(k0, A.yblk, Bp) + (size_t)b * A.yblk + tx] = v;
+                else rows_out[(size_t)b * A.Kp + k] = v;
+            }
             t[ty + 8 * q][tx] = v;
         }
     }

@@ -203,8 +203,9 @@ __device__ __forceinline__ void fwd64_body(const FwdArgs &A, const int bid, floa
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const int brow = er + 8 * q;
-        *reinterpret_cast<float4 *>(&Y_out[(size_t)(b0 + 32 * wn + brow) * Np + n0 + 32 * wm + 4 * ec]) =
-            *reinterpret_cast<const float4 *>(&T[brow][4 * ec]);
+        const size_t yo = A.yblk ? y_blocked_base(n0 + 32 * wm, A.yblk, Bp) + (size_t)(b0 + 32 * wn + brow) * A.yblk + 4 * ec
+                                 : (size_t)(b0 + 32 * wn + brow) * Np + n0 + 32 * wm + 4 * ec;
+        *reinterpret_cast<float4 *>(&Y_out[yo]) = *reinterpret_cast<const float4 *>(&T[brow][4 * ec]);
     }
 }
 

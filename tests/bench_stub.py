@@ -31,9 +31,9 @@ class BPGpu:
         assert uid == comm_unique_id() and 0 <= rank < world
         m = os.environ.get("MLGGD_DP_MODE")
         usable = self.B % 32 == 0 and world * self.B in (64, 128, 256, 512, 1024)
-        if m in ("gather", "shard") and not usable:
+        if m in ("gather", "shard", "shard_a2a") and not usable:
             raise MlggdError("mlggd error 1: MLGGD_DP_MODE=%s needs bunchsize %% 32 == 0 ..." % m)
-        self.mode = {"allreduce": 1, "gather": 2, "shard": 3}.get(m, (3 if world >= 6 else 2) if usable else 1)
+        self.mode = {"allreduce": 1, "gather": 2, "shard": 3, "shard_a2a": 4}.get(m, (3 if world >= 6 else 2) if usable else 1)
         self.world, self.rank = world, rank
 
     def load_chunk(self, inp, targ):
@@ -65,7 +65,7 @@ class BPGpu:
         return (10.0, n) if self.cls in ("fwd", "dx", "dw", "loss") else (0.0, 0)
 
     def dw_launches_per_step(self):
-        return 1 if self.mode in (0, 3) else 2 if self.mode == 2 else len(self.ls) - 1
+        return 1 if self.mode in (0, 3, 4) else 2 if self.mode == 2 else len(self.ls) - 1
 
     def kernel_work(self, cls, layer=0):
         return 3.7e9, 2.4e8

@@ -113,10 +113,11 @@ def test_the_rank_code_runs_end_to_end_on_a_stub_engine(form):
     assert d["timing"]["windows"] == 3 and len(d["timing"]["window_ms"]) == 3
     assert d["timing"]["window_ms_min"] <= d["ms_per_step"] * 4 <= d["timing"]["window_ms_max"]
     assert abs(d["value"] - 2 * 128 * 4 / (d["ms_per_step"] * 4e-3)) <= 1e-3 * d["value"]
-    assert list(d["dp_arms"]) == ["allreduce", "gather", "shard", "gather_other_granularity", "headline_mode_without_mainline",
-                                  "allreduce_unsharded_update"]     # north_star's exchange first, the launch-order switches last
+    assert list(d["dp_arms"]) == ["allreduce", "gather", "shard", "shard_a2a", "gather_other_granularity",
+                                  "headline_mode_without_mainline", "allreduce_unsharded_update"]  # north_star's exchange first, the launch-order switches last
     assert d["dp_arms"]["gather"]["same_as"] == "headline" and d["dp_arms"]["gather_other_granularity"]["MLGGD_DP_FINE"] == 1
-    for arm in ("allreduce", "shard", "gather_other_granularity", "headline_mode_without_mainline", "allreduce_unsharded_update"):
+    for arm in ("allreduce", "shard", "shard_a2a", "gather_other_granularity", "headline_mode_without_mainline",
+                "allreduce_unsharded_update"):
         assert d["dp_arms"][arm]["value"] > 0 and "dp_breakdown" in d["dp_arms"][arm]
     assert d["dp_arms"]["headline_mode_without_mainline"]["env"] == {"MLGGD_DP_MAINLINE": "0"}
     assert d["dp_arms"]["allreduce_unsharded_update"]["env"] == {"MLGGD_DP_AR_SHARD": "0"}
@@ -133,7 +134,7 @@ def test_stub_engine_arm_the_shape_rules_out_is_reported_not_fatal():
     assert r.returncode == 0, r.stderr[-3000:]
     d = _json_line(r.stdout)
     assert d["config"]["dp_mode"] == "allreduce" and d["dp_arms"]["allreduce"]["same_as"] == "headline"
-    assert "unavailable" in d["dp_arms"]["gather"] and "unavailable" in d["dp_arms"]["shard"]
+    assert "unavailable" in d["dp_arms"]["gather"] and "unavailable" in d["dp_arms"]["shard"] and "unavailable" in d["dp_arms"]["shard_a2a"]
     assert "unavailable" in d["dp_arms"]["gather_other_granularity"]
 
 

@@ -70,20 +70,21 @@ def test_config5_six_4096_layers_bunch_512(pkg, pyoracle, synth):
     ora.close()
 
 
-@pytest.mark.parametrize("mode", ["gather", "shard", "allreduce"])
+@pytest.mark.parametrize("mode", ["gather", "shard", "allreduce", "shard_a2a"])
 def test_config4_eight_ranks_at_the_real_shape(pkg, pyoracle, synth, mode):
     """BASELINE config 4 (8-GPU data parallel, ML-GGD beta 1.2) at its real shape, 2827-2048^3-257 with 128 frames
     per rank, on ONE GPU: eight ranks emulated one after the other, rank r on rows [128 r, 128 (r+1)) of each
     global minibatch of 1024 rows, against the oracle with bunchsize 1024 on the same rows.
     gather/shard: k_dwp<16,true> over 16 units of gathered frames; shard: 8 uneven row blocks per layer
-    (45 = 8 x 6 - 3 tile rows in layer 1, 32 = 8 x 4 in the others)."""
+    (45 = 8 x 6 - 3 tile rows in layer 1, 32 = 8 x 4 in the others); shard_a2a: the same blocks with the activations
+    written owner-blocked (block widths 384 and 256 units) and each virtual owner receiving only its block of them."""
     ls, B, world, steps = synth.baseline_layersizes(), 128, 8, 2
     ws, bs = synth.make_weights(ls, seed=41)
     rng = np.random.default_rng(42)
     bs = [rng.uniform(-0.1, 0.1, b.shape).astype(np.float32) for b in bs]
     inp, targ = synth.make_frames(steps * world * B, 257, 11, seed=43)
     eng = pkg.BPGpu(1, 0, ls, B, *HP, ws, bs, 1.2, 1)
-    eng.fake_world(world, sharded=mode == "shard", allreduce=mode == "allreduce")
+    eng.fake_world(world, sharded=mode == "shard", allreduce=mode == "allreduce", a2a=mode == "shard_a2a")
     ora = pyoracle.OracleNet(ls, world * B, *HP, 1.2, 1, ws, bs)
     assert eng.train(inp, targ) == steps and ora.train(inp, targ) == steps
     we, be = eng.returnWeights()

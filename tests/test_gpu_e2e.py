@@ -71,14 +71,15 @@ def test_baseline_goldens(pkg, synth, ml, beta):
     eng.close()
 
 
-@pytest.mark.parametrize("mode", ["allreduce", "gather", "shard"])
+@pytest.mark.parametrize("mode", ["allreduce", "gather", "shard", "shard_a2a"])
 @pytest.mark.parametrize("ml,beta", [(0, 2.0), (1, 1.2)])
 def test_exchange_path_on_one_rank_communicator(pkg, pyoracle, synth, monkeypatch, ml, beta, mode):
     """mlggd_comm_init(world=1): RCCL is dlopen'ed and the step takes a data-parallel exchange path --
     allreduce: unfused kernels, gradient buffers, all-reduce on the comm stream, k_apply_update;
     gather: all-gather of the gradient factors, then the fused kernel over the gathered minibatch;
     shard: the same with the update restricted to the rank's block of weight rows and W all-gathered in
-    place -- and must equal the oracle."""
+    place; shard_a2a: the sharded update with the activations written owner-blocked and exchanged by ncclSend / ncclRecv
+    pairs (an all-to-all; with one rank: to itself) -- and must equal the oracle."""
     monkeypatch.setenv("MLGGD_DP_MODE", mode)
     ls, B = [257 * 3, 256, 160, 257], 64
     ws, bs = synth.make_weights(ls, seed=5)
@@ -86,7 +87,7 @@ def test_exchange_path_on_one_rank_communicator(pkg, pyoracle, synth, monkeypatc
     eng = pkg.BPGpu(1, 0, ls, B, *HP, ws, bs, beta, ml)
     assert eng.comm_info() == (0, -1)                      # no communicator yet
     eng.comm_init(pkg.comm_unique_id(), 1, 0)
-    assert eng.dp_mode() == {"allreduce": 1, "gather": 2, "shard": 3}[mode]
+    assert eng.dp_mode() == {"allreduce": 1, "gather": 2, "shard": 3, "shard_a2a": 4}[mode]
     assert eng.comm_info() == (1, 0)                       # ncclCommCount / ncclCommUserRank: bench.py's `rccl_ranks`
     ora = pyoracle.OracleNet(ls, B, *HP, beta, ml, ws, bs)
     assert eng.train(inp, targ) == 3 and ora.train(inp, targ) == 3
@@ -102,7 +103,7 @@ def test_exchange_path_on_one_rank_communicator(pkg, pyoracle, synth, monkeypatc
     eng.close()
 
 
-@pytest.mark.parametrize("mode", ["gather", "shard", "allreduce"])
+@pytest.mark.parametrize("mode", ["gather", "shard", "allreduce", "shard_a2a"])
 @pytest.mark.parametrize("world,B", [(2, 64), (2, 128), (4, 128), (8, 128), (4, 32), (3, 50)])
 @pytest.mark.parametrize("ml,beta", [(0, 2.0), (1, 1.2)])
 def test_emulated_world_equals_one_device_with_the_global_bunch(pkg, pyoracle, synth, ml, beta, world, B, mode):
@@ -124,8 +125,8 @@ def test_emulated_world_equals_one_device_with_the_global_bunch(pkg, pyoracle, s
     steps = 2
     inp, targ = synth.make_frames(steps * world * B + 5, 40, 5, seed=10)   # + a ragged tail that is ignored
     eng = pkg.BPGpu(1, 0, ls, B, *HP, ws, bs, beta, ml)
-    eng.fake_world(world, sharded=mode == "shard", allreduce=mode == "allreduce")
-    assert eng.dp_mode() == {"allreduce": 1, "gather": 2, "shard": 3}[mode]
+    eng.fake_world(world, sharded=mode == "shard", allreduce=mode == "allreduce", a2a=mode == "shard_a2a")
+    assert eng.dp_mode() == {"allreduce": 1, "gather": 2, "shard": 3, "shard_a2a": 4}[mode]
     ora = pyoracle.OracleNet(ls, world * B, *HP, beta, ml, ws, bs)
     assert eng.train(inp, targ) == steps and ora.train(inp, targ) == steps
     we, be = eng.returnWeights()
@@ -135,6 +136,8 @@ def test_emulated_world_equals_one_device_with_the_global_bunch(pkg, pyoracle, s
         assert relmax(be[l], bo[l]) < 2e-5, l
         assert relmax(eng.debug_tensor("delta_w", l + 1), ora.tensor("delta_w", l + 1)) < 2e-4, l
         assert relmax(eng.debug_tensor("delta_b", l + 1), ora.tensor("delta_b", l + 1)) < 2e-4, l
+        if mode == "shard_a2a" and l < len(we) - 1:   # the last emulated rank's owner-blocked activations, un-blocked
+            assert relmax(eng.debug_tensor("y", l + 1), ora.tensor("y", l + 1, rows=world * B)[(world - 1) * B:]) < 2e-4, l
         if mode == "allreduce":
             assert relmax(eng.debug_tensor("grad_w", l + 1), ora.tensor("grad_w", l + 1)) < 3e-4, l
     if ml:
@@ -143,7 +146,7 @@ def test_emulated_world_equals_one_device_with_the_global_bunch(pkg, pyoracle, s
 
 
 @pytest.mark.parametrize("harness", ["one_rank_communicator", "emulated_world_of_4"])
-@pytest.mark.parametrize("mode", ["gather", "shard", "allreduce"])
+@pytest.mark.parametrize("mode", ["gather", "shard", "allreduce", "shard_a2a"])
 def test_dp_launch_order_knobs_do_not_change_a_bit(pkg, synth, monkeypatch, mode, harness):
     """MLGGD_DP_MAINLINE (critical-path collectives on the main stream), MLGGD_DP_STOPEV (events riding on
     the producing kernel's dispatch packet) and, for the all-reduce arm, MLGGD_DP_AR_SHARD (reduce-scatter -> update
@@ -166,7 +169,7 @@ def test_dp_launch_order_knobs_do_not_change_a_bit(pkg, synth, monkeypatch, mode
             monkeypatch.setenv(k, v)
         eng = pkg.BPGpu(1, 0, ls, B, *HP, ws, bs, 1.2, 1)
         if harness == "emulated_world_of_4":
-            eng.fake_world(world, sharded=mode == "shard", allreduce=mode == "allreduce")
+            eng.fake_world(world, sharded=mode == "shard", allreduce=mode == "allreduce", a2a=mode == "shard_a2a")
         else:
             eng.comm_init(pkg.comm_unique_id(), 1, 0)
         assert eng.train(inp, targ) == steps
@@ -214,7 +217,7 @@ def test_emulated_world_with_the_fine_grained_factor_exchange(pkg, pyoracle, syn
 
 
 @pytest.mark.parametrize("ml,beta", [(0, 2.0), (1, 1.2)])
-@pytest.mark.parametrize("mode", ["gather", "shard", "allreduce"])
+@pytest.mark.parametrize("mode", ["gather", "shard", "allreduce", "shard_a2a"])
 def test_frame_stream_chunks_on_the_exchange_path(pkg, synth, monkeypatch, mode, ml, beta):
     """What BPtrain_Sigmoid does on a data-parallel rank: frame-stream chunks (rows gathered on the device, the next
     minibatch staged ahead, chunks enqueued without waiting) WITH a communicator.  Through a 1-rank RCCL communicator
@@ -250,7 +253,7 @@ def test_frame_stream_chunks_on_the_exchange_path(pkg, synth, monkeypatch, mode,
         assert relmax(out[1][1], out[0][1]) < 1e-5
 
 
-@pytest.mark.parametrize("mode", ["gather", "shard", "allreduce"])
+@pytest.mark.parametrize("mode", ["gather", "shard", "allreduce", "shard_a2a"])
 @pytest.mark.parametrize("ls", [[96, 70], [75, 64, 33]])
 @pytest.mark.parametrize("ml,beta", [(0, 2.0), (1, 0.9)])
 def test_emulated_world_on_shallow_nets(pkg, pyoracle, synth, monkeypatch, ml, beta, ls, mode):
@@ -266,7 +269,7 @@ def test_emulated_world_on_shallow_nets(pkg, pyoracle, synth, monkeypatch, ml, b
         inp = rng.standard_normal((steps * world * B, ls[0]), dtype=np.float32)
         targ = rng.standard_normal((steps * world * B, ls[-1]), dtype=np.float32)
         eng = pkg.BPGpu(1, 0, ls, B, *HP, ws, bs, beta, ml)
-        eng.fake_world(world, sharded=mode == "shard", allreduce=mode == "allreduce")
+        eng.fake_world(world, sharded=mode == "shard", allreduce=mode == "allreduce", a2a=mode == "shard_a2a")
         ora = pyoracle.OracleNet(ls, world * B, *HP, beta, ml, ws, bs)
         assert eng.train(inp, targ) == steps and ora.train(inp, targ) == steps
         we, be = eng.returnWeights()
@@ -608,10 +611,11 @@ def test_bench_rehearses_the_data_parallel_path_on_one_gpu():
     d = json.loads(lines[0])
     assert "rehearsal" in d and d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and "incomplete" not in d
     assert d["config"]["dp_mode"] == "gather" and d["roofline"]["launches_timed"] == 64   # one dW launch per step (grouped exchange)
-    assert list(d["dp_arms"]) == ["allreduce", "gather", "shard", "gather_other_granularity", "headline_mode_without_mainline",
-                                  "allreduce_unsharded_update"]
+    assert list(d["dp_arms"]) == ["allreduce", "gather", "shard", "shard_a2a", "gather_other_granularity",
+                                  "headline_mode_without_mainline", "allreduce_unsharded_update"]
     assert d["dp_arms"]["gather"]["same_as"] == "headline" and d["skipped"] == []        # everything fits the default budget
-    for arm in ("allreduce", "shard", "gather_other_granularity", "headline_mode_without_mainline", "allreduce_unsharded_update"):
+    for arm in ("allreduce", "shard", "shard_a2a", "gather_other_granularity", "headline_mode_without_mainline",
+                "allreduce_unsharded_update"):
         a = d["dp_arms"][arm]
         assert a["value"] > 1e5 and a["dp_breakdown"]["compute_us_by_class"]["dw"] > 0, (arm, a)
     # the all-reduce arm updates the rank's block only (here the whole matrix: one rank) in one pass per layer

@@ -39,7 +39,7 @@ for case in range(N):
         cands = [w for w in (2, 4, 8) if w * B in (64, 128, 256, 512, 1024)]
         if cands:
             world = int(rng.choice(cands))
-    dp = ['gather', 'shard', 'allreduce'][int(rng.integers(0, 3))] if world > 1 else ''
+    dp = ['gather', 'shard', 'allreduce', 'shard_a2a'][int(rng.integers(0, 4))] if world > 1 else ''
     frames_mode = bool(world == 1 and rng.random() < 0.4)
     ws, bs = synth.make_weights(ls, seed=100 + case)
     bs = [rng.uniform(-0.1, 0.1, b.shape).astype(np.float32) for b in bs]
@@ -54,7 +54,7 @@ for case in range(N):
     tg = np.ascontiguousarray(targ_fr[first + toff])
     eng = pkg.BPGpu(1, 0, ls, B, *HP, ws, bs, beta, ml)
     if world > 1:
-        eng.fake_world(world, sharded=dp == 'shard', allreduce=dp == 'allreduce')  # rank r: rows [r*B,(r+1)*B) of each global minibatch
+        eng.fake_world(world, sharded=dp == 'shard', allreduce=dp == 'allreduce', a2a=dp == 'shard_a2a')  # rank r: rows [r*B,(r+1)*B) of each global minibatch
     ora = pyoracle.OracleNet(ls, world * B, *HP, beta, ml, ws, bs)
     if frames_mode:
         got = eng.train_frames(feat, targ_fr, first, ctx, toff)
