@@ -465,3 +465,16 @@ def shard_rows(global_frames, world_size, rank):
         raise ValueError("global minibatch %d not divisible by world size %d" % (global_frames, world_size))
     per = global_frames // world_size
     return rank * per, (rank + 1) * per
+
+
+def weight_row_block(in_units, world_size, rank):
+    """Rows [lo, hi) of a layer's weight matrix W [in][out] that `rank` owns in the sharded updates (the `shard`,
+    `shard_a2a` and `allreduce` exchanges; engine.hip shard_alloc): the ceil32-padded input width is cut into 64-row tile
+    rows, ceil(tile rows / world) of them per rank; hi is clipped to the true width, so late ranks may own fewer rows or
+    none.  Also the block of UNITS of the layer below that rank receives in the all-to-all form."""
+    kp = (int(in_units) + 31) // 32 * 32
+    tile_rows = (kp + 63) // 64
+    per = (tile_rows + world_size - 1) // world_size
+    lo = min(rank * per * 64, int(in_units))
+    hi = min((rank + 1) * per * 64, int(in_units))
+    return lo, hi

@@ -60,6 +60,15 @@ def test_shard_rows(pkg):
         pkg.shard_rows(100, 8, 0)
 
 
+def test_weight_row_blocks(pkg):
+    """The block table of the sharded updates (engine.hip shard_alloc): 64-row tile rows of the
+    ceil32-padded width, ceil(rows / world) per rank, clipped to the true width."""
+    assert [pkg.weight_row_block(2827, 8, r) for r in (0, 1, 6, 7)] == [(0, 384), (384, 768), (2304, 2688), (2688, 2827)]  # 45 = 8 x 6 - 3
+    assert [pkg.weight_row_block(2048, 8, r) for r in (0, 7)] == [(0, 256), (1792, 2048)]
+    assert [pkg.weight_row_block(96, 4, r) for r in range(4)] == [(0, 64), (64, 96), (96, 96), (96, 96)]            # late ranks own nothing
+    assert pkg.weight_row_block(300, 1, 0) == (0, 300)
+
+
 def test_create_rejects_bad_arguments_before_touching_a_device(pkg):
     """Argument checks of mlggd_create that need no GPU: a bunch larger than the loss kernels' LDS tile, a layer
     whose padded weight matrix a kernel could not address with 32-bit byte offsets."""
