@@ -4,7 +4,7 @@
 # copies and the GEMM kernels is NOT what an un-profiled run does; use it for order and per-kernel durations only.
 # usage: bash tools/dp_rehearse_trace.sh <mode> [extra env assignments...]
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; M=${1:-shard}; shift
-O=$R/gpurun_out/r03_dp_trace_$M; mkdir -p $O
+O=$R/gpurun_out/r04_dp_trace_$M; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for kv in "$@"; do export "$kv"; done
 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $O/trace -- python3 $R/bench.py --rehearse-dp --dp-mode $M --steps 20 --warmup 5 --windows 2 --no-ml --no-dp-arms --no-kernel-timing > $O/bench.json 2> $O/bench.err
