@@ -288,14 +288,14 @@ def test_epoch_horizon_one_full_chunk_of_800_steps(pkg, pyoracle, synth, ml, bet
         # kernels' own summation order with fused multiply-adds (bit-identical GEMMs, tests/test_gpu_mfma_order.py), so
         # its distance to the oracle is what the HIP path's ORDER alone does to this trajectory; the HIP path's distance
         # to IT is what libm alone (expf, powf) adds
-        names = ("split 4", "split 7", "MFMA order")
-        runs = [oracle_run(4), oracle_run(7), oracle_run(1, "hip")]
+        names = ("split 4", "split 7", "MFMA order") if beta < 1.0 else ("split 4", "MFMA order")  # (an 800-step oracle run takes ~20-40 s)
+        runs = [oracle_run(4)] + ([oracle_run(7)] if beta < 1.0 else []) + [oracle_run(1, "hip")]
         twins = [dist(r, ora) for r in runs]
         yard = {k: max(t[k] for t in twins) for k in twins[0]}
         for nm, t in zip(names, twins):
             print("   oracle order twin (%s) vs oracle: sqerr %.1e abserr %.1e loglik %.1e | alpha relrms %.1e relmax %.1e | "
                   "weights relrms %.1e relmax %.1e" % (nm, t["sq"], t["ab"], t["ll"], t["alpha"], t["alpha_max"], t["w"], t["w_max"]))
-        t = dist(hip, runs[2])
+        t = dist(hip, runs[-1])
         print("   HIP vs the MFMA-order twin (libm only): sqerr %.1e abserr %.1e loglik %.1e | alpha relrms %.1e relmax %.1e | "
               "weights relrms %.1e relmax %.1e" % (t["sq"], t["ab"], t["ll"], t["alpha"], t["alpha_max"], t["w"], t["w_max"]))
         # beta = 0.9, measured r03: HIP vs oracle 8.7e-5 / 5.2e-5 / 9.4e-5 (all three inside the north_star's 1e-4 this
