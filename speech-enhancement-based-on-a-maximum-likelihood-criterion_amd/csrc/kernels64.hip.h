@@ -368,17 +368,18 @@ __device__ __forceinline__ void dx64_body(const DxArgs &A, const int bid, float 
 // when it belongs to the NEXT tile -- so no per-unit hand-off is left (k_dwp waits, barriers and re-reads its first
 // fragments with nothing beside them once per 64 frames: 85 % MFMA-pipe occupancy at 512 frames against 94 % for
 // k_fwd64).  Per tile of NCH = 2 H chunks, one body per chunk, fully unrolled; the extras ride in groups 4..7 of fixed bodies:
-//   body 0: the previous tile's accumulators -> wave-private scratch (16 ds_write_b32), the record of tile t+2 fetched
-//   body 1: scratch read back as 4 x 16 bytes per lane
-//   body 2: momentum / weight-decay update of the previous tile with ITS W / delta (loaded one tile ago) + 8 stores
-//   body 3, 4: this tile's W, delta -> the register set body 2 has just freed (consumed in the next tile's body 2)
+//   body 0: the previous tile's accumulators -> scratch (16 ds_write_b32) and back as 4 x 16 bytes per lane; the record of
+//           tile t+2 fetched.  The scratch of wave w is the part of ring buffer 0 that only wave w's DMA writes (its 8 rows
+//           of each operand piece: 2 x 2 KB): chunk 0 was consumed a body ago, chunk 4 arrives in body 1
+//   body 1: momentum / weight-decay update of the previous tile with ITS W / delta (loaded one tile ago) + 8 stores
+//   body 2, 3: this tile's W, delta -> the register set body 1 has just freed (consumed in the next tile's body 1)
 // The counted waits follow from that placement: body j's wait retires the DMA of chunk j+1 (issued in body j-2), so it
-// leaves the 8 DMAs of bodies j-1, j in flight + the extras of bodies j-2, j-1: vmcnt 8, 9, 9, 16, 20, 16, 12, 8, 8...
+// leaves the 8 DMAs of bodies j-1, j in flight + the extras of bodies j-2, j-1: vmcnt 8, 9, 17, 20, 16, 12, 8, 8...
 // (vmcnt counts in issue order).  The bias gradient of a weight-row-block-0 tile (kernAccSumrow order) is read from dEdX in
 // global memory between tiles: 1 tile in 64 at k = 4096.
-// LDS: the ring (64 KB) + 4 KB of scratch per wave = 80 KB: two workgroups per CU.
+// LDS: the ring alone (64 KB): two workgroups per CU.
 // ---------------------------------------------------------------------------------------
-constexpr int dwr_lds_floats() { return T64_NB * T64_CH + 4 * 1024; }
+constexpr int dwr_lds_floats() { return T64_NB * T64_CH; }
 
 template <int H, bool FUSED, bool POW2>
 __device__ __forceinline__ void dwr_body(const DwpDesc *__restrict__ table, const int total, const DwpConst C, const int bid,
@@ -404,7 +405,10 @@ __device__ __forceinline__ void dwr_body(const DwpDesc *__restrict__ table, cons
 #define DWR_RANGE_B(T) (DWR_VALID(T) ? (size_t)(32 * NCH) * (T).Np * 4 : (size_t)0)
     const int r4 = lane >> 4, q16 = lane & 15, er = lane >> 3, ec = lane & 7;
     const int fo = h * 64 + i;
-    float *scr = smem + T64_NB * T64_CH + wave * 1024;  // wave-private transposition scratch [32][32]
+    // wave-private transposition scratch [32][32] inside ring buffer 0: rows 0..15 in the wave's rows of the A piece,
+    // rows 16..31 in its rows of the B piece
+    float *scr0 = smem + 2 * wave * 256, *scr1 = smem + 2048 + 2 * wave * 256;
+#define DWR_SCR(ROW, COL) (((ROW) < 16 ? scr0 : scr1 - 512)[(ROW) * 32 + (COL)])
 
     f32x16 acc, accp;
 #pragma unroll
@@ -443,8 +447,8 @@ __device__ __forceinline__ void dwr_body(const DwpDesc *__restrict__ table, cons
 #define DWR_BODY(FA, FB, NA, NB, J)                                                                \
     {                                                                                              \
         constexpr int j_ = (J);                                                                    \
-        constexpr int vm_ = j_ == 1 || j_ == 2 ? 9 : j_ == 3 ? (FUSED ? 16 : 12) : j_ == 4 ? (FUSED ? 20 : 12) \
-                            : j_ == 5 ? (FUSED ? 16 : 8) : j_ == 6 ? (FUSED ? 12 : 8) : 8;        \
+        constexpr int vm_ = j_ == 1 ? 9 : j_ == 2 ? (FUSED ? 17 : 13) : j_ == 3 ? (FUSED ? 20 : 12)  \
+                            : j_ == 4 ? (FUSED ? 16 : 8) : j_ == 5 ? (FUSED ? 12 : 8) : 8;        \
         __builtin_amdgcn_s_waitcnt(0xC07F);                                                        \
         _Pragma("unroll") for (int g = 0; g < 4; g++) {                                            \
             acc = mfma32(FA[2 * g], FB[2 * g], acc);                                               \
@@ -460,15 +464,18 @@ __device__ __forceinline__ void dwr_body(const DwpDesc *__restrict__ table, cons
             acc = mfma32(FA[2 * g + 1], FB[2 * g + 1], acc);                                       \
             DWR_RD4((j_ + 1) & 3, NA, NB, g - 4);                                                  \
             if (j_ == 0) {                                                                         \
-                _Pragma("unroll") for (int r = 4 * (g - 4); r < 4 * (g - 4) + 4; r++)              \
-                    scr[acc_row(r, lane) * 32 + i] = accp[r];                                      \
+                if (g < 6) {                                                                       \
+                    _Pragma("unroll") for (int r = 8 * (g - 4); r < 8 * (g - 4) + 8; r++)          \
+                        DWR_SCR(acc_row(r, lane), i) = accp[r];                                    \
+                } else {                                                                           \
+                    if (g == 6) __builtin_amdgcn_wave_barrier();                                   \
+                    _Pragma("unroll") for (int q = 2 * (g - 6); q < 2 * (g - 6) + 2; q++)          \
+                        gq[q] = *reinterpret_cast<const float4 *>(&DWR_SCR(er + 8 * q, 4 * ec));   \
+                    asm volatile("" ::: "memory");                                                 \
+                }                                                                                  \
                 if (g == 7) tnn_raw = DWR_FETCH(t + 2 * nblocks);                                  \
             }                                                                                      \
             if (j_ == 1) {                                                                         \
-                gq[g - 4] = *reinterpret_cast<const float4 *>(&scr[(er + 8 * (g - 4)) * 32 + 4 * ec]); \
-                asm volatile("" ::: "memory");                                                     \
-            }                                                                                      \
-            if (j_ == 2) {                                                                         \
                 const int q_ = g - 4, off_ = DWR_OFF(tp, q_);                                      \
                 const float4 g4_ = gq[q_];                                                         \
                 if (FUSED) { /* kernUpdatedelta (DevFunc.cu:502) then kernAccSum (DevFunc.cu:440) */ \
@@ -484,8 +491,8 @@ __device__ __forceinline__ void dwr_body(const DwpDesc *__restrict__ table, cons
                     bstore4(g4_, rWp, off_);                                                       \
                 }                                                                                  \
             }                                                                                      \
-            if (FUSED && j_ == 3) pw[g - 4] = bload4(rWc, DWR_OFF(tc, g - 4), 0);                  \
-            if (FUSED && j_ == 4) pd[g - 4] = bload4(rDc, DWR_OFF(tc, g - 4), 0);                  \
+            if (FUSED && j_ == 2) pw[g - 4] = bload4(rWc, DWR_OFF(tc, g - 4), 0);                  \
+            if (FUSED && j_ == 3) pd[g - 4] = bload4(rDc, DWR_OFF(tc, g - 4), 0);                  \
             __builtin_amdgcn_sched_barrier(0);                                                     \
         }                                                                                          \
     }
@@ -586,11 +593,11 @@ __device__ __forceinline__ void dwr_body(const DwpDesc *__restrict__ table, cons
     {
         const rsrc_t rWp = make_rsrc(tp.W, tp.szW), rDp = make_rsrc(tp.D, FUSED ? tp.szW : 0);
 #pragma unroll
-        for (int r = 0; r < 16; r++) scr[acc_row(r, lane) * 32 + i] = accp[r];
+        for (int r = 0; r < 16; r++) DWR_SCR(acc_row(r, lane), i) = accp[r];
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const float4 g4_ = *reinterpret_cast<const float4 *>(&scr[(er + 8 * q) * 32 + 4 * ec]);
+            const float4 g4_ = *reinterpret_cast<const float4 *>(&DWR_SCR(er + 8 * q, 4 * ec));
             const int off_ = DWR_OFF(tp, q);
             if (FUSED) {
                 const float4 w = pw[q];
@@ -611,6 +618,7 @@ __device__ __forceinline__ void dwr_body(const DwpDesc *__restrict__ table, cons
 #undef DWR_RANGE_A
 #undef DWR_RANGE_B
 #undef DWR_OFF
+#undef DWR_SCR
 #undef DWR_DMA
 #undef DWR_RD4
 #undef DWR_BODY
