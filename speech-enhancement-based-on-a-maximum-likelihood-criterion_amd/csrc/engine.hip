@@ -221,9 +221,6 @@ struct mlggd_engine {
     // 64 x 64-tile forward / dX kernels (kernels64.hip.h): 1 = where the shape gives every CU such a tile (units and
     // frames multiples of 64, tiles >= CUs), 0 = never, 2 = wherever the shape divides (tests, A/B); MLGGD_TILE64
     int tile64 = 1, n_cus = 256;
-    // persistent dW + update kernel on the 4-chunk operand ring (k_dwr, kernels64.hip.h) for tiles of >= 4 units of 64
-    // frames: 1 = on, 0 = k_dwp everywhere (A/B); MLGGD_DWR
-    int dwr = 1;
     int fwd_nw = 4, dx_nw = 4, dw_tile = 1, dw_persist = 1, dwp_per_cu = 2, dw_merge = 1, loss_fuse = 1, tile_map = 0, stage_ahead = 1;  // dw_tile 0 = auto
 
     // data parallel
@@ -827,25 +824,6 @@ static int launch_dwp_t(mlggd_engine *e, const DwpJobs &J, bool fused, hipStream
         return launch_check("k_dwp_bias");
     }
     CHK(dwp_table(e, J, fused, grid, &table));
-    if constexpr (H >= 4) {
-        if (e->dwr) {  // 256+ frames per tile: the same walk on the forward kernel's operand ring (no per-unit hand-off)
-            const size_t ldsr = dwr_lds_floats() * sizeof(float);
-            unsigned nbr;
-            memcpy(&nbr, &C.nf, sizeof(nbr));
-            const bool p2 = (nbr & 0x007FFFFFu) == 0u && C.nf >= 1.0f;
-#define DWR_LAUNCH(FUSED_, POW2_)                                                                          \
-    {                                                                                                      \
-        CHK(ensure_lds(e, k_dwr<H, FUSED_, POW2_>, ldsr));                                                 \
-        launch_timed(e, k_dwr<H, FUSED_, POW2_>, dim3(grid), dim3(256), ldsr, st, table, J.total, C);      \
-    }
-            if (fused && p2) DWR_LAUNCH(true, true)
-            else if (fused) DWR_LAUNCH(true, false)
-            else if (p2) DWR_LAUNCH(false, true)
-            else DWR_LAUNCH(false, false)
-#undef DWR_LAUNCH
-            return launch_check("k_dwr");
-        }
-    }
     if constexpr (H == 2 || H == 8) {
         if (e->stamp_class == KC_DW && e->stamp_layer == -1 && e->stamp_buf && fused && C.nf == 128.0f) {
             // diagnostic: the twin kernel with per-phase cycle sums (rows grid .. 2*grid-1 of the stamp buffer)
@@ -1621,7 +1599,6 @@ int mlggd_create(const mlggd_config *cfg, const float *const *weights, const flo
     if (const char *v = getenv("MLGGD_STAGE_AHEAD")) e->stage_ahead = atoi(v);
     if (const char *v = getenv("MLGGD_CV_DEVICE")) e->cv_device = atoi(v) ? 1 : 0;
     if (const char *v = getenv("MLGGD_TILE64")) e->tile64 = atoi(v);
-    if (const char *v = getenv("MLGGD_DWR")) e->dwr = atoi(v);
     *out = e;  // so the caller can destroy on failure
 
     roctx_load();

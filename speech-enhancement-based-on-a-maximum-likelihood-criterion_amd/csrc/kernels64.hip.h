@@ -359,275 +359,6 @@ __device__ __forceinline__ void dx64_body(const DxArgs &A, const int bid, float 
     }
 }
 
-// ---------------------------------------------------------------------------------------
-// Weight gradient + fused SGD update for tiles of >= 4 units of 64 frames (256+ frames), persistent:
-//   G[k][n] = sum_b Y[b][k] dEdX[b][n];  delta = mom delta - lr (G / n_frames + wc W);  W = delta + 1.0f W
-// k_dwp's walk (host-built 64-byte tile records, 2 workgroups per CU, the epilogue of tile t inside tile t+1, bit-identical
-// chain per weight over the frames in order) ON the forward kernel's operand ring: the stream of (tile, 32-frame chunk)
-// pairs runs through the 4-chunk LDS-DMA ring without a seam -- chunk j+3 is requested while chunk j's MFMAs run, also
-// when it belongs to the NEXT tile -- so no per-unit hand-off is left (k_dwp waits, barriers and re-reads its first
-// fragments with nothing beside them once per 64 frames: 85 % MFMA-pipe occupancy at 512 frames against 94 % for
-// k_fwd64).  Per tile of NCH = 2 H chunks, one body per chunk, fully unrolled; the extras ride in groups 4..7 of fixed bodies:
-//   body 0: the previous tile's accumulators -> scratch (16 ds_write_b32) and back as 4 x 16 bytes per lane; the record of
-//           tile t+2 fetched.  The scratch of wave w is the part of ring buffer 0 that only wave w's DMA writes (its 8 rows
-//           of each operand piece: 2 x 2 KB): chunk 0 was consumed a body ago, chunk 4 arrives in body 1
-//   body 1: momentum / weight-decay update of the previous tile with ITS W / delta (loaded one tile ago) + 8 stores
-//   body 2, 3: this tile's W, delta -> the register set body 1 has just freed (consumed in the next tile's body 1)
-// The counted waits follow from that placement: body j's wait retires the DMA of chunk j+1 (issued in body j-2), so it
-// leaves the 8 DMAs of bodies j-1, j in flight + the extras of bodies j-2, j-1: vmcnt 8, 9, 17, 20, 16, 12, 8, 8...
-// (vmcnt counts in issue order).  The bias gradient of a weight-row-block-0 tile (kernAccSumrow order) is read from dEdX in
-// global memory between tiles: 1 tile in 64 at k = 4096.
-// LDS: the ring alone (64 KB): two workgroups per CU.
-// ---------------------------------------------------------------------------------------
-constexpr int dwr_lds_floats() { return T64_NB * T64_CH; }
-
-template <int H, bool FUSED, bool POW2>
-__device__ __forceinline__ void dwr_body(const DwpDesc *__restrict__ table, const int total, const DwpConst C, const int bid,
-                                         const int nblocks, float *smem) {
-    constexpr int NCH = 2 * H;
-    static_assert(NCH >= 8 && NCH % 4 == 0, "the ring index of a tile's chunk j is j & 3");
-    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
-    const int i = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
-    const float nf = C.nf, mom = C.mom, lr = C.lr, wc = C.wc, inv_nf = 1.0f / nf;
-    constexpr int OOB = 0x7FFFFF00;
-    int t = bid;
-    if (t >= total) return;
-    const rsrc_t rT = make_rsrc(table, ((size_t)total + 2 * (size_t)nblocks) * sizeof(DwpDesc));
-    const int voT = 16 * (lane & 3);
-#define DWR_FETCH(TI) __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rT, voT, (TI) * 64, 0))
-    DwpDesc tc = dwp_decode(DWR_FETCH(t)), tn = dwp_decode(DWR_FETCH(t + nblocks)), tp = tc;
-    tp.packed = 0;
-    tp.szW = 0;
-    u32x4 tnn_raw = {0u, 0u, 0u, 0u};  // the record of tile t + 2 nblocks: fetched in body 0 of every tile
-#define DWR_VALID(T) ((((T).packed >> 24) & 1u) != 0u)
-    // operand ranges end with the tile's last frame row (an invalid record: range 0 -> every access out of range)
-#define DWR_RANGE_A(T) (DWR_VALID(T) ? (size_t)(32 * NCH) * (T).ldA * 4 : (size_t)0)
-#define DWR_RANGE_B(T) (DWR_VALID(T) ? (size_t)(32 * NCH) * (T).Np * 4 : (size_t)0)
-    const int r4 = lane >> 4, q16 = lane & 15, er = lane >> 3, ec = lane & 7;
-    const int fo = h * 64 + i;
-    // wave-private transposition scratch [32][32] inside ring buffer 0: rows 0..15 in the wave's rows of the A piece,
-    // rows 16..31 in its rows of the B piece
-    float *scr0 = smem + 2 * wave * 256, *scr1 = smem + 2048 + 2 * wave * 256;
-#define DWR_SCR(ROW, COL) (((ROW) < 16 ? scr0 : scr1 - 512)[(ROW) * 32 + (COL)])
-
-    f32x16 acc, accp;
-#pragma unroll
-    for (int r = 0; r < 16; r++) acc[r] = accp[r] = 0.0f;
-    float4 pw[4], pd[4], gq[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) pw[q] = pd[q] = gq[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-    float fa[16], fb[16], ga[16], gb[16];
-    // this lane's float4 number q of the wave tile of record T: byte offset, out of range past the matrix
-#define DWR_OFF(T, Q)                                                                              \
-    (((32 * wm + er + 8 * (Q)) < (int)((T).packed & 0xFFu) && (32 * wn + 4 * ec) < (int)(((T).packed >> 8) & 0xFFu)) \
-         ? ((32 * wm + er + 8 * (Q)) * (T).Np + 32 * wn + 4 * ec) * 4                             \
-         : OOB)
-    // chunk CH (0..NCH-1) of tile T into ring buffer BUF: this wave's instruction Q (0, 1: rows of A; 2, 3: rows of B)
-#define DWR_DMA(T, RA, RB, CH, BUF, Q)                                                            \
-    {                                                                                              \
-        const int t_ = 2 * wave + ((Q) & 1);                                                       \
-        float *dst_ = smem + (BUF) * T64_CH + t_ * 256;                                            \
-        if ((Q) < 2)                                                                               \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(RA, T64_LDSP(dst_), 16, (r4 * (T).ldA + 4 * q16) * 4, \
-                                                     (32 * (CH) + 4 * t_) * (T).ldA * 4, 0, 0);   \
-        else                                                                                       \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(RB, T64_LDSP(dst_ + 2048), 16, (r4 * (T).Np + 4 * q16) * 4, \
-                                                     (32 * (CH) + 4 * t_) * (T).Np * 4, 0, 0);    \
-    }
-#define DWR_RD4(BUF, NA, NB, Q)                                                                    \
-    {                                                                                              \
-        const float *b_ = smem + (BUF) * T64_CH + fo;                                              \
-        _Pragma("unroll") for (int u = 4 * (Q); u < 4 * (Q) + 4; u++) {                           \
-            NA[u] = b_[u * 128 + 32 * wm];                                                         \
-            NB[u] = b_[2048 + u * 128 + 32 * wn];                                                  \
-        }                                                                                          \
-    }
-    // body J (a compile-time constant) of the current tile: chunk J on (FA, FB); chunk J+3 of the stream requested
-    // (of the next tile from J = NCH-3 on); chunk J+1 read from the ring; the extras of the header comment
-#define DWR_BODY(FA, FB, NA, NB, J)                                                                \
-    {                                                                                              \
-        constexpr int j_ = (J);                                                                    \
-        constexpr int vm_ = j_ == 1 ? 9 : j_ == 2 ? (FUSED ? 17 : 13) : j_ == 3 ? (FUSED ? 20 : 12)  \
-                            : j_ == 4 ? (FUSED ? 16 : 8) : j_ == 5 ? (FUSED ? 12 : 8) : 8;        \
-        __builtin_amdgcn_s_waitcnt(0xC07F);                                                        \
-        _Pragma("unroll") for (int g = 0; g < 4; g++) {                                            \
-            acc = mfma32(FA[2 * g], FB[2 * g], acc);                                               \
-            acc = mfma32(FA[2 * g + 1], FB[2 * g + 1], acc);                                       \
-            if (j_ + 3 < NCH) DWR_DMA(tc, rAc, rBc, j_ + 3, (j_ + 3) & 3, g)                      \
-            else DWR_DMA(tn, rAn, rBn, j_ + 3 - NCH, (j_ + 3) & 3, g)                             \
-            __builtin_amdgcn_sched_barrier(0);                                                     \
-        }                                                                                          \
-        __builtin_amdgcn_s_waitcnt(0x0F70 | (vm_ & 15) | ((vm_ >> 4) << 14));                     \
-        __builtin_amdgcn_s_barrier();                                                              \
-        _Pragma("unroll") for (int g = 4; g < 8; g++) {                                            \
-            acc = mfma32(FA[2 * g], FB[2 * g], acc);                                               \
-            acc = mfma32(FA[2 * g + 1], FB[2 * g + 1], acc);                                       \
-            DWR_RD4((j_ + 1) & 3, NA, NB, g - 4);                                                  \
-            if (j_ == 0) {                                                                         \
-                if (g < 6) {                                                                       \
-                    _Pragma("unroll") for (int r = 8 * (g - 4); r < 8 * (g - 4) + 8; r++)          \
-                        DWR_SCR(acc_row(r, lane), i) = accp[r];                                    \
-                } else {                                                                           \
-                    if (g == 6) __builtin_amdgcn_wave_barrier();                                   \
-                    _Pragma("unroll") for (int q = 2 * (g - 6); q < 2 * (g - 6) + 2; q++)          \
-                        gq[q] = *reinterpret_cast<const float4 *>(&DWR_SCR(er + 8 * q, 4 * ec));   \
-                    asm volatile("" ::: "memory");                                                 \
-                }                                                                                  \
-                if (g == 7) tnn_raw = DWR_FETCH(t + 2 * nblocks);                                  \
-            }                                                                                      \
-            if (j_ == 1) {                                                                         \
-                const int q_ = g - 4, off_ = DWR_OFF(tp, q_);                                      \
-                const float4 g4_ = gq[q_];                                                         \
-                if (FUSED) { /* kernUpdatedelta (DevFunc.cu:502) then kernAccSum (DevFunc.cu:440) */ \
-                    const float4 w = pw[q_];                                                       \
-                    float4 d = pd[q_];                                                             \
-                    d.x = mom * d.x - lr * ((POW2 ? g4_.x * inv_nf : g4_.x / nf) + wc * w.x);      \
-                    d.y = mom * d.y - lr * ((POW2 ? g4_.y * inv_nf : g4_.y / nf) + wc * w.y);      \
-                    d.z = mom * d.z - lr * ((POW2 ? g4_.z * inv_nf : g4_.z / nf) + wc * w.z);      \
-                    d.w = mom * d.w - lr * ((POW2 ? g4_.w * inv_nf : g4_.w / nf) + wc * w.w);      \
-                    bstore4(d, rDp, off_);                                                         \
-                    bstore4(make_float4(d.x + 1.0f * w.x, d.y + 1.0f * w.y, d.z + 1.0f * w.z, d.w + 1.0f * w.w), rWp, off_); \
-                } else {                                                                           \
-                    bstore4(g4_, rWp, off_);                                                       \
-                }                                                                                  \
-            }                                                                                      \
-            if (FUSED && j_ == 2) pw[g - 4] = bload4(rWc, DWR_OFF(tc, g - 4), 0);                  \
-            if (FUSED && j_ == 3) pd[g - 4] = bload4(rDc, DWR_OFF(tc, g - 4), 0);                  \
-            __builtin_amdgcn_sched_barrier(0);                                                     \
-        }                                                                                          \
-    }
-    // prologue: the first tile's chunks 0..2
-    {
-        const rsrc_t rAc = make_rsrc(tc.A, DWR_RANGE_A(tc)), rBc = make_rsrc(tc.Bm, DWR_RANGE_B(tc));
-#pragma unroll
-        for (int c = 0; c < 3; c++)
-#pragma unroll
-            for (int q = 0; q < 4; q++) DWR_DMA(tc, rAc, rBc, c, c, q)
-    }
-    __builtin_amdgcn_s_waitcnt(0x0F70 | 8);
-    __builtin_amdgcn_s_barrier();
-#pragma unroll
-    for (int q = 0; q < 4; q++) DWR_RD4(0, fa, fb, q);
-    __builtin_amdgcn_sched_barrier(0);
-    for (;;) {
-        const rsrc_t rAc = make_rsrc(tc.A, DWR_RANGE_A(tc)), rBc = make_rsrc(tc.Bm, DWR_RANGE_B(tc));
-        const rsrc_t rAn = make_rsrc(tn.A, DWR_RANGE_A(tn)), rBn = make_rsrc(tn.Bm, DWR_RANGE_B(tn));
-        const rsrc_t rWc = make_rsrc(tc.W, tc.szW), rDc = make_rsrc(tc.D, FUSED ? tc.szW : 0);
-        const rsrc_t rWp = make_rsrc(tp.W, tp.szW), rDp = make_rsrc(tp.D, FUSED ? tp.szW : 0);
-        DWR_BODY(fa, fb, ga, gb, 0)
-        DWR_BODY(ga, gb, fa, fb, 1)
-        DWR_BODY(fa, fb, ga, gb, 2)
-        DWR_BODY(ga, gb, fa, fb, 3)
-        DWR_BODY(fa, fb, ga, gb, 4)
-        DWR_BODY(ga, gb, fa, fb, 5)
-        DWR_BODY(fa, fb, ga, gb, 6)
-        DWR_BODY(ga, gb, fa, fb, 7)
-        if constexpr (NCH >= 16) {
-            DWR_BODY(fa, fb, ga, gb, 8)
-            DWR_BODY(ga, gb, fa, fb, 9)
-            DWR_BODY(fa, fb, ga, gb, 10)
-            DWR_BODY(ga, gb, fa, fb, 11)
-            DWR_BODY(fa, fb, ga, gb, 12)
-            DWR_BODY(ga, gb, fa, fb, 13)
-            DWR_BODY(fa, fb, ga, gb, 14)
-            DWR_BODY(ga, gb, fa, fb, 15)
-        }
-        if constexpr (NCH >= 32) {
-            DWR_BODY(fa, fb, ga, gb, 16)
-            DWR_BODY(ga, gb, fa, fb, 17)
-            DWR_BODY(fa, fb, ga, gb, 18)
-            DWR_BODY(ga, gb, fa, fb, 19)
-            DWR_BODY(fa, fb, ga, gb, 20)
-            DWR_BODY(ga, gb, fa, fb, 21)
-            DWR_BODY(fa, fb, ga, gb, 22)
-            DWR_BODY(ga, gb, fa, fb, 23)
-            DWR_BODY(fa, fb, ga, gb, 24)
-            DWR_BODY(ga, gb, fa, fb, 25)
-            DWR_BODY(fa, fb, ga, gb, 26)
-            DWR_BODY(ga, gb, fa, fb, 27)
-            DWR_BODY(fa, fb, ga, gb, 28)
-            DWR_BODY(ga, gb, fa, fb, 29)
-            DWR_BODY(fa, fb, ga, gb, 30)
-            DWR_BODY(ga, gb, fa, fb, 31)
-        }
-        // bias gradient + update of a weight-row-block-0 tile (kernAccSumrow, DevFunc.cu:267-285 <- BP_GPU.cu:434,435,437):
-        // frames added sequentially, read from global memory (rare tile; its loads drain what is in flight: a stall, not a hazard)
-        {
-            const int nbias = (int)((tc.packed >> 16) & 0xFFu);
-            if (tid < nbias) {
-                const rsrc_t rBc_ = make_rsrc(tc.Bm, DWR_RANGE_B(tc));
-                const int B = C.B;
-                float sb = bload(rBc_, tid * 4, 0);
-                int b = 1;
-                for (; b + 16 <= B; b += 16) {
-                    float v[16];
-#pragma unroll
-                    for (int u = 0; u < 16; u++) v[u] = bload(rBc_, tid * 4, (b + u) * tc.Np * 4);
-#pragma unroll
-                    for (int u = 0; u < 16; u++) sb += v[u];
-                }
-                for (; b < B; b++) sb += bload(rBc_, tid * 4, b * tc.Np * 4);
-                const rsrc_t rb_ = make_rsrc(tc.bias, 256), rdb_ = make_rsrc(tc.dbias, FUSED ? 256 : 0);
-                if (FUSED) {
-                    const float bv = bload(rb_, tid * 4, 0);
-                    const float d = mom * bload(rdb_, tid * 4, 0) - lr * ((POW2 ? sb * inv_nf : sb / nf) + 0.0f * bv);
-                    bstore1(d, rdb_, tid * 4);
-                    bstore1(d + 1.0f * bv, rb_, tid * 4);
-                } else {
-                    bstore1(sb, rb_, tid * 4);
-                }
-            }
-        }
-        // the tile's accumulators and record become "previous": their epilogue rides in the next tile's bodies 0..2
-        accp = acc;
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[r] = 0.0f;
-        tp = tc;
-        t += nblocks;
-        if (t >= total) break;
-        tc = tn;
-        tn = dwp_decode(tnn_raw);
-    }
-    // epilogue of the last tile (tp): nothing left to hide it behind
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    {
-        const rsrc_t rWp = make_rsrc(tp.W, tp.szW), rDp = make_rsrc(tp.D, FUSED ? tp.szW : 0);
-#pragma unroll
-        for (int r = 0; r < 16; r++) DWR_SCR(acc_row(r, lane), i) = accp[r];
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const float4 g4_ = *reinterpret_cast<const float4 *>(&DWR_SCR(er + 8 * q, 4 * ec));
-            const int off_ = DWR_OFF(tp, q);
-            if (FUSED) {
-                const float4 w = pw[q];
-                float4 d = pd[q];
-                d.x = mom * d.x - lr * ((POW2 ? g4_.x * inv_nf : g4_.x / nf) + wc * w.x);
-                d.y = mom * d.y - lr * ((POW2 ? g4_.y * inv_nf : g4_.y / nf) + wc * w.y);
-                d.z = mom * d.z - lr * ((POW2 ? g4_.z * inv_nf : g4_.z / nf) + wc * w.z);
-                d.w = mom * d.w - lr * ((POW2 ? g4_.w * inv_nf : g4_.w / nf) + wc * w.w);
-                bstore4(d, rDp, off_);
-                bstore4(make_float4(d.x + 1.0f * w.x, d.y + 1.0f * w.y, d.z + 1.0f * w.z, d.w + 1.0f * w.w), rWp, off_);
-            } else {
-                bstore4(g4_, rWp, off_);
-            }
-        }
-    }
-#undef DWR_FETCH
-#undef DWR_VALID
-#undef DWR_RANGE_A
-#undef DWR_RANGE_B
-#undef DWR_OFF
-#undef DWR_SCR
-#undef DWR_DMA
-#undef DWR_RD4
-#undef DWR_BODY
-}
-
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void k_fwd64(FwdArgs A) { fwd64_body<MODE>(A, (int)blockIdx.x, g_dyn_lds); }
 __global__ __launch_bounds__(256, 2) void k_dx64(DxArgs A) { dx64_body(A, (int)blockIdx.x, g_dyn_lds); }
-template <int H, bool FUSED, bool POW2>
-__global__ __launch_bounds__(256, 2) void k_dwr(const DwpDesc *__restrict__ table, int total, DwpConst C) {
-    dwr_body<H, FUSED, POW2>(table, total, C, (int)blockIdx.x, (int)gridDim.x, g_dyn_lds);
-}

@@ -360,38 +360,6 @@ def test_launch_plan_knobs_do_not_change_a_bit(pkg, synth, monkeypatch, frames_m
             assert np.array_equal(x, y), (env, split)
 
 
-@pytest.mark.parametrize("ls,B", [([40 * 5, 192, 100, 40], 256), ([257 * 3, 320, 257], 512), ([40 * 5, 96, 40], 1024)])
-@pytest.mark.parametrize("ml,beta", [(0, 2.0), (1, 1.2)])
-def test_the_ring_dw_kernel_is_bit_identical_to_the_unit_one(pkg, synth, monkeypatch, ls, B, ml, beta):
-    """k_dwr (csrc/kernels64.hip.h; the dW + update kernel from 256 frames on: k_dwp's walk on the forward kernel's
-    operand ring) takes the same host-built tile records as k_dwp and chains every weight over the frames in the same
-    order, so the two must leave the same bits: weights, biases, delta after 3 steps, widths that are not multiples
-    of 64 (half tiles, the 257th unit) and 4 / 8 / 16 units of 64 frames included.  MLGGD_DWR=0 switches it off;
-    MLGGD_DW_MERGE=0: one launch per layer (short tile walks: some workgroups get one tile, some none)."""
-    ws, bs = synth.make_weights(ls, seed=31)
-    rng = np.random.default_rng(32)
-    bs = [rng.uniform(-0.1, 0.1, b.shape).astype(np.float32) for b in bs]
-    inp, targ = synth.make_frames(3 * B, ls[-1], ls[0] // ls[-1], seed=33)
-
-    def run(env):
-        for k in ("MLGGD_DWR", "MLGGD_DW_MERGE"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        eng = pkg.BPGpu(1, 0, ls, B, *HP, ws, bs, beta, ml)
-        assert eng.train(inp, targ) == 3
-        w, b = eng.returnWeights()
-        out = [x.copy() for x in w + b] + [eng.debug_tensor("delta_w", l + 1) for l in range(len(ls) - 1)] + \
-              [eng.debug_tensor("delta_b", l + 1) for l in range(len(ls) - 1)]
-        eng.close()
-        return out
-
-    base = run({"MLGGD_DWR": "0"})
-    for env in ({}, {"MLGGD_DW_MERGE": "0"}):
-        for i, (x, y) in enumerate(zip(run(env), base)):
-            assert np.array_equal(x, y), (env, i)
-
-
 def test_chunks_enqueued_without_waiting_equal_chunks_trained_one_by_one(pkg, synth):
     """mlggd_train_frames_async: four chunks of different sizes back to back (the upload of chunk i+1 goes to
     the other device buffer set while chunk i's steps run, the host arrays are overwritten right after each
