@@ -651,11 +651,12 @@ def rank_main(args):
     if dp and not args.no_dp_arms:
         # The other gradient exchanges on the same ranks, same data, same windows, ordered by what they decide: first
         # BASELINE.json's own exchange (the all-reduce of the weight gradients: reduce-scatter -> update of the rank's
-        # block -> all-gather of W), then the engine's default and its sharded form, then the launch-order switches
+        # block -> all-gather of W), then the all-to-all form of the sharded update (the one exchange whose link
+        # arithmetic fits >= 6x at 8 ranks), then the factor all-gather in both forms, then the launch-order switches
         # whose defaults rest on one-GPU rehearsals (MLGGD_DP_FINE, MLGGD_DP_MAINLINE, MLGGD_DP_AR_SHARD).
         fine_default = os.environ.get("MLGGD_DP_FINE")
-        arm_specs = [("allreduce", "allreduce", None), ("gather", "gather", None), ("shard", "shard", None),
-                     ("shard_a2a", "shard_a2a", None),
+        arm_specs = [("allreduce", "allreduce", None), ("shard_a2a", "shard_a2a", None), ("gather", "gather", None),
+                     ("shard", "shard", None),
                      ("gather_other_granularity", "gather", {"MLGGD_DP_FINE": "0" if fine_default == "1" else "1"}),
                      ("headline_mode_without_mainline", DP_MODE_NAME[mode], {"MLGGD_DP_MAINLINE": "0"}),
                      ("allreduce_unsharded_update", "allreduce", {"MLGGD_DP_AR_SHARD": "0"})]

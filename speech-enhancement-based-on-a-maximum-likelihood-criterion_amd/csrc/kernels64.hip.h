@@ -30,13 +30,14 @@ static_assert(4 * T64_SCR <= T64_NB * T64_CH, "the epilogue scratch aliases the 
 #define T64_LDSP(p) ((__attribute__((address_space(3))) void *)(p))
 
 // ---------------------------------------------------------------------------------------
-// The main loop the forward and the weight-gradient kernel share: C[64 x 64] += A^T B over `nch` chunks of 32 reduction
+// The main loop of the forward kernel (the weight-gradient experiments of round 4 ran on it too): C[64 x 64] += A^T B over `nch` chunks of 32 reduction
 // rows, both operands row-major with the reduction index as the ROW ([32][64] pieces: forward: W[k][n], Yt[k][b];
 // dW: Y[b][k], dEdX[b][n]).  4 waves as 2 x 2 (wm: half of A's columns, wn: half of B's); ring of 4 chunks, DMA three
 // chunks ahead, one barrier per chunk in the middle of its MFMA block.
 // after_prologue(): called once between the DMAs of chunks 0..2 and the first wait; it may issue EXTRA (template) more
-// vector-memory loads per lane (the dW kernel's W / delta tiles): vmcnt counts in issue order, so bodies 0 and 1 -- whose
-// awaited chunks 1, 2 are OLDER than those loads -- leave them in flight, and from body 2 on they have arrived.
+// vector-memory loads per lane (used by the dW experiments of round 4, profiles/r04_dw64_ab.txt; the forward kernel passes
+// 0): vmcnt counts in issue order, so bodies 0 and 1 -- whose awaited chunks 1, 2 are OLDER than those loads -- leave
+// them in flight, and from body 2 on they have arrived.
 // endA / endB: a byte offset at or past the end of the resource's range -- where the chunks past the last one are
 // "loaded" from (out of range for every lane: no memory request).
 // ---------------------------------------------------------------------------------------

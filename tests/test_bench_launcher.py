@@ -113,7 +113,7 @@ def test_the_rank_code_runs_end_to_end_on_a_stub_engine(form):
     assert d["timing"]["windows"] == 3 and len(d["timing"]["window_ms"]) == 3
     assert d["timing"]["window_ms_min"] <= d["ms_per_step"] * 4 <= d["timing"]["window_ms_max"]
     assert abs(d["value"] - 2 * 128 * 4 / (d["ms_per_step"] * 4e-3)) <= 1e-3 * d["value"]
-    assert list(d["dp_arms"]) == ["allreduce", "gather", "shard", "shard_a2a", "gather_other_granularity",
+    assert list(d["dp_arms"]) == ["allreduce", "shard_a2a", "gather", "shard", "gather_other_granularity",
                                   "headline_mode_without_mainline", "allreduce_unsharded_update"]  # north_star's exchange first, the launch-order switches last
     assert d["dp_arms"]["gather"]["same_as"] == "headline" and d["dp_arms"]["gather_other_granularity"]["MLGGD_DP_FINE"] == 1
     for arm in ("allreduce", "shard", "shard_a2a", "gather_other_granularity", "headline_mode_without_mainline",

@@ -611,7 +611,7 @@ def test_bench_rehearses_the_data_parallel_path_on_one_gpu():
     d = json.loads(lines[0])
     assert "rehearsal" in d and d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and "incomplete" not in d
     assert d["config"]["dp_mode"] == "gather" and d["roofline"]["launches_timed"] == 64   # one dW launch per step (grouped exchange)
-    assert list(d["dp_arms"]) == ["allreduce", "gather", "shard", "shard_a2a", "gather_other_granularity",
+    assert list(d["dp_arms"]) == ["allreduce", "shard_a2a", "gather", "shard", "gather_other_granularity",
                                   "headline_mode_without_mainline", "allreduce_unsharded_update"]
     assert d["dp_arms"]["gather"]["same_as"] == "headline" and d["skipped"] == []        # everything fits the default budget
     for arm in ("allreduce", "shard", "shard_a2a", "gather_other_granularity", "headline_mode_without_mainline",
