@@ -123,7 +123,7 @@ def test_the_rank_code_runs_end_to_end_on_a_stub_engine(form):
     assert d["dp_arms"]["allreduce_unsharded_update"]["env"] == {"MLGGD_DP_AR_SHARD": "0"}
     assert d["dp_breakdown"]["compute_us_by_class"]["fwd"] == 10.0 and "ml_ggd" in d and "dp_breakdown" in d["ml_ggd"]
     assert d["ml_ggd"]["stat_comm"]["env"] == {"MLGGD_DP_STAT_COMM": "1"}
-    assert "incomplete" not in d and d["skipped"] == [] and d["budget_s"] == 240.0
+    assert "incomplete" not in d and d["skipped"] == [] and d["budget_s"] == 300.0
     assert "bench.py headline after" in r.stderr     # the early copy of the headline
 
 
