@@ -237,3 +237,25 @@ def test_mfma_order_twin_is_the_same_function_in_another_summation_order(pyoracl
     assert np.array_equal(a.tensor("out", rows=B), c.tensor("out", rows=B))
     for o in (base, twin, a, c):
         o.close()
+
+
+def test_mfma_order_twin_matches_its_goldens_bit_exact(pyoracle, synth):
+    """tests/golden/mfma_order_twin.npz (oracle/make_golden.py twin()): the restated HIP summation order, with 4-wave
+    layers, an output layer over 3 slabs, and a mixed per-layer kernel plan (64 x 64-tile layers = one chain)."""
+    g = np.load(os.path.join(GOLD, "mfma_order_twin.npz"))
+    ls, B = [15, 8, 8, 8, 5], 8
+    for s_out, plan, key in ((1, None, "s1_w4"), (3, None, "s3_w4"), (1, [(1, 4), (1, 1), (4, 1), (4, 4)], "s1_plan")):
+        ws, bs = synth.make_weights(ls, seed=3)
+        inp, targ = synth.make_frames(3 * B, 5, 3, seed=4)
+        pyoracle.set_gemm_order("hip", s_out, plan=plan)
+        try:
+            o = pyoracle.OracleNet(ls, B, *HP, 1.2, 1, ws, bs)
+            o.train(inp, targ)
+        finally:
+            pyoracle.set_gemm_order("ref")
+        w, b = o.get_weights()
+        for l in range(4):
+            assert np.array_equal(w[l], g["%s_W%d" % (key, l + 1)]), (key, l)
+            assert np.array_equal(b[l], g["%s_b%d" % (key, l + 1)]), (key, l)
+        assert np.array_equal(o.tensor("scalefactor"), g[key + "_alpha"])
+        o.close()
