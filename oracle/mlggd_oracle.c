@@ -236,29 +236,45 @@ ORA_FMA static void gemm_fwd_hip(int B, int K, int N, const float *Y, const floa
     }
 }
 
+/* (dEdX is transposed once to [unit][frame] so that the chains of a unit's B frames -- independent of one another -- run
+ * side by side in vector lanes: the order WITHIN every chain is untouched) */
+static float *transpose_bn(int B, int N, const float *x) {
+    float *t = (float *)malloc((size_t)N * B * sizeof(float));
+#pragma omp parallel for schedule(static)
+    for (int j = 0; j < N; j++)
+        for (int b = 0; b < B; b++) t[(size_t)j * B + b] = x[(size_t)b * N + j];
+    return t;
+}
 ORA_FMA static void gemm_dx_hip(int B, int K, int N, const float *dEdX, const float *W, float *dEdY, int NW) {
     const int Q = ceil32i(N) / 4, qw = (Q + NW - 1) / NW;
-#pragma omp parallel for schedule(static)
-    for (int k = 0; k < K; k++) {
-        const float *w = W + (size_t)k * N;
-        for (int b = 0; b < B; b++) {
-            const float *d = dEdX + (size_t)b * N;
-            float tot = 0.0f;
+    float *dT = transpose_bn(B, N, dEdX);
+#pragma omp parallel
+    {
+        float *part = (float *)malloc((size_t)B * sizeof(float)), *tot = (float *)malloc((size_t)B * sizeof(float));
+#pragma omp for schedule(static)
+        for (int k = 0; k < K; k++) {
+            const float *w = W + (size_t)k * N;
             for (int wv = 0; wv < NW; wv++) {
                 const int q0 = wv * qw, qend = q0 + qw < Q ? q0 + qw : Q;
-                float part = 0.0f;
+                for (int b = 0; b < B; b++) part[b] = 0.0f;
                 for (int q = q0; q < qend; q++) {
                     static const int ord[4] = {0, 2, 1, 3};
                     for (int t = 0; t < 4; t++) {
                         const int j = 4 * q + ord[t];
-                        if (j < N) part = __builtin_fmaf(w[j], d[j], part); /* columns j >= N are zero pads */
+                        if (j >= N) continue; /* columns j >= N are zero pads */
+                        const float wj = w[j];
+                        const float *d = dT + (size_t)j * B;
+                        for (int b = 0; b < B; b++) part[b] = __builtin_fmaf(wj, d[b], part[b]);
                     }
                 }
-                tot = wv == 0 ? part : tot + part;
+                for (int b = 0; b < B; b++) tot[b] = wv == 0 ? part[b] : tot[b] + part[b];
             }
-            dEdY[(size_t)b * K + k] = tot;
+            for (int b = 0; b < B; b++) dEdY[(size_t)b * K + k] = tot[b];
         }
+        free(part);
+        free(tot);
     }
+    free(dT);
 }
 
 ORA_FMA static void gemm_dw_hip(int B, int K, int N, const float *Y, const float *dEdX, float *G) {
@@ -317,22 +333,31 @@ static void gemm_fwd(int B, int K, int N, const float *Y, const float *W, float 
  * ((s0+s1)+(s2+s3))+((s4+s5)+(s6+s7)). */
 static void gemm_dx(int B, int K, int N, const float *dEdX, const float *W, float *dEdY) {
     const int S = g_gemm_split;
-    if (S > 1) { /* order twin: S contiguous ranges of j, each ascending from 0.0f, added in range order */
-#pragma omp parallel for schedule(static)
-        for (int k = 0; k < K; k++) {
-            const float *w = W + (size_t)k * N;
-            for (int b = 0; b < B; b++) {
-                const float *d = dEdX + (size_t)b * N;
-                float tot = 0.0f;
+    if (S > 1) { /* order twin: S contiguous ranges of j, each ascending from 0.0f, added in range order (the frames'
+                  * independent chains side by side in vector lanes: dEdX transposed once) */
+        float *dT = transpose_bn(B, N, dEdX);
+#pragma omp parallel
+        {
+            float *part = (float *)malloc((size_t)B * sizeof(float)), *tot = (float *)malloc((size_t)B * sizeof(float));
+#pragma omp for schedule(static)
+            for (int k = 0; k < K; k++) {
+                const float *w = W + (size_t)k * N;
                 for (int sp = 0; sp < S; sp++) {
                     const int j_lo = (int)((long)N * sp / S), j_hi = (int)((long)N * (sp + 1) / S);
-                    float part = 0.0f;
-                    for (int j = j_lo; j < j_hi; j++) part += d[j] * w[j];
-                    tot = sp == 0 ? part : tot + part;
+                    for (int b = 0; b < B; b++) part[b] = 0.0f;
+                    for (int j = j_lo; j < j_hi; j++) {
+                        const float wj = w[j];
+                        const float *d = dT + (size_t)j * B;
+                        for (int b = 0; b < B; b++) part[b] += d[b] * wj;
+                    }
+                    for (int b = 0; b < B; b++) tot[b] = sp == 0 ? part[b] : tot[b] + part[b];
                 }
-                dEdY[(size_t)b * K + k] = tot;
+                for (int b = 0; b < B; b++) dEdY[(size_t)b * K + k] = tot[b];
             }
+            free(part);
+            free(tot);
         }
+        free(dT);
         return;
     }
 #pragma omp parallel for schedule(static)
