@@ -2362,6 +2362,8 @@ int mlggd_comm_init(mlggd_handle e, const void *id, int world_size, int rank) {
                 return fail(MLGGD_ERR_ARG, "MLGGD_DP_MODE=%s needs bunchsize %% 32 == 0 and world*bunchsize in {64,128,256,512,1024}", m);
             mode = !strcmp(m, "gather") ? 1 : 2;
             e->dp_a2a = !strcmp(m, "shard_a2a") ? 1 : 0;  // opt-in only: no default or threshold changes before a scaling record exists
+            if (e->dp_a2a && e->cfg.dropoutflag == 1)
+                return fail(MLGGD_ERR_ARG, "MLGGD_DP_MODE=shard_a2a: dropout masks the row-major activations, which this mode keeps blocked by owner");
         }
     }
     CHK(rccl_load());
@@ -2409,6 +2411,7 @@ int mlggd_debug_fake_world(mlggd_handle e, int world_size, int mode) {
     e->fake_world = true;
     e->dp_mode = mode == 2 ? 0 : (mode == 1 || mode == 3) ? 2 : 1;
     e->dp_a2a = mode == 3 ? 1 : 0;
+    if (e->dp_a2a && e->cfg.dropoutflag == 1) return fail(MLGGD_ERR_ARG, "fake world: dropout is not supported with the all-to-all form");
     dp_knobs(e);
     CHK(create_comm_stream(e));
     CHK(dev_alloc(e, &e->colsum_tot, e->Dp));
