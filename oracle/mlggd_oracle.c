@@ -193,10 +193,242 @@ void ora_set_gemm_plan(int layer, int fwd_waves, int dx_waves) {
 #define ORA_FMA __attribute__((target("fma"))) /* fmaf as ONE instruction; -ffp-contract=off still keeps every other a*b+c unfused */
 static int ceil32i(int x) { return (x + 31) & ~31; }
 
+
+/* ---- register-blocked forms of the three GEMMs (speed only).
+ * The plain loops in gemm_fwd / gemm_dx / gemm_dw (and their *_hip twins) DEFINE the oracle: one chain per output
+ * element, operands and order as documented there.  The blocked forms run the SAME chains -- same operands, same
+ * order, same unfused (or, for the twins, fused) operations -- only laid out so that the independent chains of a
+ * tile of outputs sit side by side in vector registers instead of going through memory after every term.  Nothing
+ * is re-associated: tests/test_oracle.py::test_blocked_gemms_equal_the_plain_loops_bit_for_bit compares the two
+ * forms on ragged shapes, and ora_set_gemm_blocked(0) switches back to the plain loops. */
+static int g_gemm_blocked = 1;
+void ora_set_gemm_blocked(int on) { g_gemm_blocked = on != 0; }
+
+#include <immintrin.h>
+typedef float v8f __attribute__((vector_size(32)));
+typedef float v8fu __attribute__((vector_size(32), aligned(4), may_alias));
+static inline v8f ld8(const float *p) { return *(const v8fu *)p; }
+static inline void st8(float *p, v8f v) { *(v8fu *)p = v; }
+static inline v8f bc8(float x) { return (v8f){x, x, x, x, x, x, x, x}; }
+#define ORA_MAC_PLAIN(c, a, b) ((c) + (a) * (b))                          /* -ffp-contract=off: a multiply, then an add */
+#define ORA_MAC_FUSED(c, a, b) ((v8f)_mm256_fmadd_ps((__m256)(a), (__m256)(b), (__m256)(c))) /* one rounding */
+
+/* out[i][0..15] = sum over t = t_lo .. t_hi-1 (ascending, from 0.0f) of a_i[t] * bp[t][0..15], i = 0..3: the 64 chains
+ * of a 4 x 16 tile in 8 registers.  Forward: a_i = four frames' rows of Y, t = k, bp = a 16-column panel of W.
+ * dW: a_i = four units' rows of Y^T, t = frame, bp = a 16-column panel of dEdX. */
+#define ORA_DEF_TILE_4X16(NAME, ATTR, MAC)                                                                             \
+    ATTR static inline void NAME(int t_lo, int t_hi, const float *a0, const float *a1, const float *a2,                \
+                                 const float *a3, const float *bp, float *out) {                                       \
+        const v8f z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};                                                        \
+        v8f c00 = z, c01 = z, c10 = z, c11 = z, c20 = z, c21 = z, c30 = z, c31 = z;                                    \
+        for (int t = t_lo; t < t_hi; t++) {                                                                            \
+            const v8f b0 = ld8(bp + (size_t)16 * t), b1 = ld8(bp + (size_t)16 * t + 8);                                \
+            v8f a = bc8(a0[t]);                                                                                        \
+            c00 = MAC(c00, a, b0); c01 = MAC(c01, a, b1);                                                              \
+            a = bc8(a1[t]);                                                                                            \
+            c10 = MAC(c10, a, b0); c11 = MAC(c11, a, b1);                                                              \
+            a = bc8(a2[t]);                                                                                            \
+            c20 = MAC(c20, a, b0); c21 = MAC(c21, a, b1);                                                              \
+            a = bc8(a3[t]);                                                                                            \
+            c30 = MAC(c30, a, b0); c31 = MAC(c31, a, b1);                                                              \
+        }                                                                                                              \
+        st8(out, c00); st8(out + 8, c01); st8(out + 16, c10); st8(out + 24, c11);                                      \
+        st8(out + 32, c20); st8(out + 40, c21); st8(out + 48, c30); st8(out + 56, c31);                                \
+    }
+ORA_DEF_TILE_4X16(tile_4x16, , ORA_MAC_PLAIN)
+ORA_DEF_TILE_4X16(tile_4x16_fused, ORA_FMA, ORA_MAC_FUSED)
+
+/* columns [j0, j0+16) of the rows [0, R) of M[R][N] as a dense [R][16] panel, zero beyond column N */
+static void pack_panel16(int R, int N, int j0, const float *M, float *panel) {
+    const int jw = N - j0 < 16 ? N - j0 : 16;
+    for (int r = 0; r < R; r++) {
+        const float *src = M + (size_t)r * N + j0;
+        float *dst = panel + (size_t)16 * r;
+        if (jw == 16) { st8(dst, ld8(src)); st8(dst + 8, ld8(src + 8)); }
+        else for (int j = 0; j < 16; j++) dst[j] = j < jw ? src[j] : 0.0f;
+    }
+}
+
+/* Forward, blocked.  The reduction index is cut into n_slab x n_per contiguous ranges [k_lo[s], k_hi[s]); every range
+ * is one chain from 0.0f, the n_per partial sums of a slab are added in order, the slabs are added in order, then
+ * + old X.  (1 x 1: the documented order; 1 x S: the split twin; s_out x waves: the MFMA-order twin.) */
+#define ORA_MAX_RANGES 64
+#define ORA_DEF_FWD_BLOCKED(NAME, ATTR, TILE)                                                                          \
+    ATTR static void NAME(int B, int K, int N, const float *Y, const float *W, float *X, int n_slab, int n_per,        \
+                          const int *k_lo, const int *k_hi) {                                                          \
+        const int nblk = (N + 15) / 16;                                                                                \
+        _Pragma("omp parallel")                                                                                        \
+        {                                                                                                              \
+            float *wp = (float *)malloc((size_t)K * 16 * sizeof(float));                                               \
+            float part[64], slab[64], tot[64];                                                                         \
+            _Pragma("omp for schedule(dynamic, 1)")                                                                    \
+            for (int jb = 0; jb < nblk; jb++) {                                                                        \
+                const int j0 = jb * 16, jw = N - j0 < 16 ? N - j0 : 16;                                                \
+                pack_panel16(K, N, j0, W, wp);                                                                         \
+                for (int b0 = 0; b0 < B; b0 += 4) {                                                                    \
+                    const float *a[4];                                                                                 \
+                    for (int i = 0; i < 4; i++) a[i] = Y + (size_t)(b0 + i < B ? b0 + i : B - 1) * K;                  \
+                    for (int sl = 0; sl < n_slab; sl++) {                                                              \
+                        for (int w = 0; w < n_per; w++) {                                                              \
+                            const int s = sl * n_per + w;                                                              \
+                            TILE(k_lo[s], k_hi[s], a[0], a[1], a[2], a[3], wp, part);                                  \
+                            for (int i = 0; i < 64; i++) slab[i] = w == 0 ? part[i] : slab[i] + part[i];               \
+                        }                                                                                              \
+                        for (int i = 0; i < 64; i++) tot[i] = sl == 0 ? slab[i] : tot[i] + slab[i];                    \
+                    }                                                                                                  \
+                    for (int i = 0; i < 4 && b0 + i < B; i++) {                                                        \
+                        float *x = X + (size_t)(b0 + i) * N + j0;                                                      \
+                        for (int j = 0; j < jw; j++) x[j] = tot[16 * i + j] + x[j];                                    \
+                    }                                                                                                  \
+                }                                                                                                      \
+            }                                                                                                          \
+            free(wp);                                                                                                  \
+        }                                                                                                              \
+    }
+ORA_DEF_FWD_BLOCKED(gemm_fwd_blocked, , tile_4x16)
+ORA_DEF_FWD_BLOCKED(gemm_fwd_blocked_fused, ORA_FMA, tile_4x16_fused)
+
+static float *transpose_rows(int R, int C, const float *x) { /* x[R][C] -> t[C][R] */
+    float *t = (float *)malloc((size_t)R * C * sizeof(float));
+#pragma omp parallel for schedule(static)
+    for (int c = 0; c < C; c++)
+        for (int r = 0; r < R; r++) t[(size_t)c * R + r] = x[(size_t)r * C + c];
+    return t;
+}
+
+/* dW, blocked: G[k][j] = chain over the frames b = 0..B-1 ascending from 0.0f of Y[b][k] * dEdX[b][j] */
+#define ORA_DEF_DW_BLOCKED(NAME, ATTR, TILE)                                                                           \
+    ATTR static void NAME(int B, int K, int N, const float *Y, const float *dEdX, float *G) {                          \
+        enum { KC = 128 };                                                                                             \
+        float *yt = transpose_rows(B, K, Y); /* [K][B]: a unit's frames contiguous */                                  \
+        const int nblk = (N + 15) / 16, nkc = (K + KC - 1) / KC;                                                       \
+        _Pragma("omp parallel")                                                                                        \
+        {                                                                                                              \
+            float *dp = (float *)malloc((size_t)B * 16 * sizeof(float));                                               \
+            float out[64];                                                                                             \
+            _Pragma("omp for schedule(dynamic, 1) collapse(2)")                                                        \
+            for (int jb = 0; jb < nblk; jb++)                                                                          \
+                for (int kc = 0; kc < nkc; kc++) {                                                                     \
+                    const int j0 = jb * 16, jw = N - j0 < 16 ? N - j0 : 16;                                            \
+                    const int k_end = (kc + 1) * KC < K ? (kc + 1) * KC : K;                                           \
+                    pack_panel16(B, N, j0, dEdX, dp);                                                                  \
+                    for (int k0 = kc * KC; k0 < k_end; k0 += 4) {                                                      \
+                        const float *a[4];                                                                             \
+                        for (int i = 0; i < 4; i++) a[i] = yt + (size_t)(k0 + i < K ? k0 + i : K - 1) * B;             \
+                        TILE(0, B, a[0], a[1], a[2], a[3], dp, out);                                                   \
+                        for (int i = 0; i < 4 && k0 + i < k_end; i++) {                                                \
+                            float *g = G + (size_t)(k0 + i) * N + j0;                                                  \
+                            for (int j = 0; j < jw; j++) g[j] = out[16 * i + j];                                       \
+                        }                                                                                              \
+                    }                                                                                                  \
+                }                                                                                                      \
+            free(dp);                                                                                                  \
+        }                                                                                                              \
+        free(yt);                                                                                                      \
+    }
+ORA_DEF_DW_BLOCKED(gemm_dw_blocked, , tile_4x16)
+ORA_DEF_DW_BLOCKED(gemm_dw_blocked_fused, ORA_FMA, tile_4x16_fused)
+
+/* dX in the documented order, blocked: per output element the eight interleaved partial sums q = j mod 8 ARE the
+ * eight lanes of one register; a tile of 2 frames x 4 units keeps its 8 such registers live over the whole row. */
+static void gemm_dx_blocked(int B, int K, int N, const float *dEdX, const float *W, float *dEdY) {
+    const int n8 = N / 8;
+#pragma omp parallel for schedule(static)
+    for (int k0 = 0; k0 < K; k0 += 4) {
+        const float *w[4];
+        for (int m = 0; m < 4; m++) w[m] = W + (size_t)(k0 + m < K ? k0 + m : K - 1) * N;
+        for (int b0 = 0; b0 < B; b0 += 2) {
+            const float *d[2];
+            for (int i = 0; i < 2; i++) d[i] = dEdX + (size_t)(b0 + i < B ? b0 + i : B - 1) * N;
+            const v8f z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            v8f c[2][4] = {{z, z, z, z}, {z, z, z, z}};
+            for (int j8 = 0; j8 < n8; j8++) {
+                const v8f d0 = ld8(d[0] + 8 * j8), d1 = ld8(d[1] + 8 * j8);
+                for (int m = 0; m < 4; m++) {
+                    const v8f wv = ld8(w[m] + 8 * j8);
+                    c[0][m] = c[0][m] + d0 * wv;
+                    c[1][m] = c[1][m] + d1 * wv;
+                }
+            }
+            for (int i = 0; i < 2 && b0 + i < B; i++)
+                for (int m = 0; m < 4 && k0 + m < K; m++) {
+                    float s[8];
+                    st8(s, c[i][m]);
+                    for (int q = 0, j = 8 * n8; j + q < N; q++) s[q] += d[i][j + q] * w[m][j + q];
+                    dEdY[(size_t)(b0 + i) * K + k0 + m] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+                }
+        }
+    }
+}
+
+/* dX with the reduction cut into ranges (the split twin and the MFMA-order twin), blocked: the B frames' chains of a
+ * unit are independent, so they run in vector lanes (dEdX transposed once to [unit][frame], frames padded to 16 with
+ * zeros); a tile of 16 frames x 4 units keeps its 8 registers live over a whole range.  jseq lists the reduction
+ * indices of range r in the order they are consumed, [start[r], start[r+1]); every range is one chain from 0.0f and
+ * the ranges' partial sums are added in range order. */
+#define ORA_DEF_DXT_BLOCKED(NAME, ATTR, MAC)                                                                           \
+    ATTR static void NAME(int B, int K, int N, const float *dEdX, const float *W, float *dEdY, int nranges,            \
+                          const int *start, const int *jseq) {                                                         \
+        const int B16 = (B + 15) & ~15;                                                                                \
+        float *dT = (float *)calloc((size_t)N * B16, sizeof(float));                                                   \
+        _Pragma("omp parallel for schedule(static)")                                                                   \
+        for (int j = 0; j < N; j++)                                                                                    \
+            for (int b = 0; b < B; b++) dT[(size_t)j * B16 + b] = dEdX[(size_t)b * N + j];                             \
+        _Pragma("omp parallel for schedule(static)")                                                                   \
+        for (int k0 = 0; k0 < K; k0 += 4) {                                                                            \
+            const float *w[4];                                                                                         \
+            for (int m = 0; m < 4; m++) w[m] = W + (size_t)(k0 + m < K ? k0 + m : K - 1) * N;                          \
+            for (int b0 = 0; b0 < B16; b0 += 16) {                                                                     \
+                const v8f z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};                                                \
+                v8f tot[4][2];                                                                                         \
+                for (int r = 0; r < nranges; r++) {                                                                    \
+                    v8f c00 = z, c01 = z, c10 = z, c11 = z, c20 = z, c21 = z, c30 = z, c31 = z;                        \
+                    for (int t = start[r]; t < start[r + 1]; t++) {                                                    \
+                        const int j = jseq[t];                                                                         \
+                        const v8f d0 = ld8(dT + (size_t)j * B16 + b0), d1 = ld8(dT + (size_t)j * B16 + b0 + 8);        \
+                        v8f a = bc8(w[0][j]);                                                                          \
+                        c00 = MAC(c00, a, d0); c01 = MAC(c01, a, d1);                                                  \
+                        a = bc8(w[1][j]);                                                                              \
+                        c10 = MAC(c10, a, d0); c11 = MAC(c11, a, d1);                                                  \
+                        a = bc8(w[2][j]);                                                                              \
+                        c20 = MAC(c20, a, d0); c21 = MAC(c21, a, d1);                                                  \
+                        a = bc8(w[3][j]);                                                                              \
+                        c30 = MAC(c30, a, d0); c31 = MAC(c31, a, d1);                                                  \
+                    }                                                                                                  \
+                    if (r == 0) {                                                                                      \
+                        tot[0][0] = c00; tot[0][1] = c01; tot[1][0] = c10; tot[1][1] = c11;                            \
+                        tot[2][0] = c20; tot[2][1] = c21; tot[3][0] = c30; tot[3][1] = c31;                            \
+                    } else {                                                                                           \
+                        tot[0][0] += c00; tot[0][1] += c01; tot[1][0] += c10; tot[1][1] += c11;                        \
+                        tot[2][0] += c20; tot[2][1] += c21; tot[3][0] += c30; tot[3][1] += c31;                        \
+                    }                                                                                                  \
+                }                                                                                                      \
+                for (int m = 0; m < 4 && k0 + m < K; m++) {                                                            \
+                    float o[16];                                                                                       \
+                    st8(o, tot[m][0]); st8(o + 8, tot[m][1]);                                                          \
+                    for (int i = 0; i < 16 && b0 + i < B; i++) dEdY[(size_t)(b0 + i) * K + k0 + m] = o[i];             \
+                }                                                                                                      \
+            }                                                                                                          \
+        }                                                                                                              \
+        free(dT);                                                                                                      \
+    }
+ORA_DEF_DXT_BLOCKED(gemm_dxT_blocked, , ORA_MAC_PLAIN)
+ORA_DEF_DXT_BLOCKED(gemm_dxT_blocked_fused, ORA_FMA, ORA_MAC_FUSED)
+
 ORA_FMA static void gemm_fwd_hip(int B, int K, int N, const float *Y, const float *W, float *X, int S, int NW) {
     enum { JB = 128 };
     const int nblk = (N + JB - 1) / JB;
     const int P = ceil32i(K) / 2, nslots = S * NW;
+    if (g_gemm_blocked && nslots <= ORA_MAX_RANGES) {
+        int lo[ORA_MAX_RANGES], hi[ORA_MAX_RANGES];
+        for (int slot = 0; slot < nslots; slot++) {
+            lo[slot] = 2 * (int)((unsigned)(P * slot) / (unsigned)nslots);
+            hi[slot] = 2 * (int)((unsigned)(P * (slot + 1)) / (unsigned)nslots);
+            if (hi[slot] > K) hi[slot] = K; /* rows k >= K are zero pads */
+        }
+        gemm_fwd_blocked_fused(B, K, N, Y, W, X, S, NW, lo, hi);
+        return;
+    }
 #pragma omp parallel
     {
         float *tot = (float *)malloc((size_t)B * JB * sizeof(float));
@@ -247,6 +479,22 @@ static float *transpose_bn(int B, int N, const float *x) {
 }
 ORA_FMA static void gemm_dx_hip(int B, int K, int N, const float *dEdX, const float *W, float *dEdY, int NW) {
     const int Q = ceil32i(N) / 4, qw = (Q + NW - 1) / NW;
+    if (g_gemm_blocked && NW <= ORA_MAX_RANGES) {
+        int start[ORA_MAX_RANGES + 1], n = 0;
+        int *jseq = (int *)malloc((size_t)4 * Q * sizeof(int));
+        for (int wv = 0; wv < NW; wv++) {
+            const int q0 = wv * qw, qend = q0 + qw < Q ? q0 + qw : Q;
+            static const int ord[4] = {0, 2, 1, 3};
+            start[wv] = n;
+            for (int q = q0; q < qend; q++)
+                for (int t = 0; t < 4; t++)
+                    if (4 * q + ord[t] < N) jseq[n++] = 4 * q + ord[t]; /* columns j >= N are zero pads */
+        }
+        start[NW] = n;
+        gemm_dxT_blocked_fused(B, K, N, dEdX, W, dEdY, NW, start, jseq);
+        free(jseq);
+        return;
+    }
     float *dT = transpose_bn(B, N, dEdX);
 #pragma omp parallel
     {
@@ -278,6 +526,7 @@ ORA_FMA static void gemm_dx_hip(int B, int K, int N, const float *dEdX, const fl
 }
 
 ORA_FMA static void gemm_dw_hip(int B, int K, int N, const float *Y, const float *dEdX, float *G) {
+    if (g_gemm_blocked) { gemm_dw_blocked_fused(B, K, N, Y, dEdX, G); return; }
 #pragma omp parallel for schedule(static)
     for (int k = 0; k < K; k++) {
         float *g = G + (size_t)k * N;
@@ -294,6 +543,15 @@ static void gemm_fwd(int B, int K, int N, const float *Y, const float *W, float 
     enum { JB = 128 };
     const int nblk = (N + JB - 1) / JB;
     const int S = g_gemm_split;
+    if (g_gemm_blocked && S <= ORA_MAX_RANGES) {
+        int lo[ORA_MAX_RANGES], hi[ORA_MAX_RANGES];
+        for (int sp = 0; sp < S; sp++) {
+            lo[sp] = (int)((long)K * sp / S);
+            hi[sp] = (int)((long)K * (sp + 1) / S);
+        }
+        gemm_fwd_blocked(B, K, N, Y, W, X, 1, S, lo, hi);
+        return;
+    }
 #pragma omp parallel
     {
         float *acc = (float *)malloc((size_t)B * JB * sizeof(float));
@@ -333,6 +591,15 @@ static void gemm_fwd(int B, int K, int N, const float *Y, const float *W, float 
  * ((s0+s1)+(s2+s3))+((s4+s5)+(s6+s7)). */
 static void gemm_dx(int B, int K, int N, const float *dEdX, const float *W, float *dEdY) {
     const int S = g_gemm_split;
+    if (S > 1 && g_gemm_blocked && S <= ORA_MAX_RANGES) {
+        int start[ORA_MAX_RANGES + 1];
+        int *jseq = (int *)malloc((size_t)(N > 0 ? N : 1) * sizeof(int));
+        for (int j = 0; j < N; j++) jseq[j] = j;
+        for (int sp = 0; sp <= S; sp++) start[sp] = (int)((long)N * sp / S);
+        gemm_dxT_blocked(B, K, N, dEdX, W, dEdY, S, start, jseq);
+        free(jseq);
+        return;
+    }
     if (S > 1) { /* order twin: S contiguous ranges of j, each ascending from 0.0f, added in range order (the frames'
                   * independent chains side by side in vector lanes: dEdX transposed once) */
         float *dT = transpose_bn(B, N, dEdX);
@@ -360,6 +627,7 @@ static void gemm_dx(int B, int K, int N, const float *dEdX, const float *W, floa
         free(dT);
         return;
     }
+    if (g_gemm_blocked) { gemm_dx_blocked(B, K, N, dEdX, W, dEdY); return; }
 #pragma omp parallel for schedule(static)
     for (int k = 0; k < K; k++) {
         const float *w = W + (size_t)k * N;
@@ -378,6 +646,7 @@ static void gemm_dx(int B, int K, int N, const float *dEdX, const float *W, floa
 /* SgemmNT, DevFunc.h:77-87 <- BP_GPU.cu:432 : G[K][N] = Y[B][K]^T . dEdX[B][N] (beta 0).
  * Order: b = 0..B-1 ascending from 0.0f. */
 static void gemm_dw(int B, int K, int N, const float *Y, const float *dEdX, float *G) {
+    if (g_gemm_blocked) { gemm_dw_blocked(B, K, N, Y, dEdX, G); return; }
 #pragma omp parallel for schedule(static)
     for (int k = 0; k < K; k++) {
         float *g = G + (size_t)k * N;

@@ -54,6 +54,7 @@ def lib(variant="strict"):
         L.ora_num_threads.restype = C.c_int
         L.ora_set_num_threads.argtypes = [C.c_int]
         L.ora_set_gemm_split.argtypes = [C.c_int]
+        L.ora_set_gemm_blocked.argtypes = [C.c_int]
         L.ora_set_gemm_order.argtypes = [C.c_int, C.c_int]
         L.ora_set_gemm_plan.argtypes = [C.c_int, C.c_int, C.c_int]
         if "OMP_NUM_THREADS" not in os.environ:
@@ -222,6 +223,12 @@ def set_gemm_split(s, variant="strict"):
     S > 1 = forward / dX reductions as S contiguous partial sums (what a split-K GEMM does).  Tests use the distance
     between the two to say what a mere change of summation order -- which cuBLAS leaves open -- does to a run."""
     lib(variant).ora_set_gemm_split(int(s))
+
+
+def set_gemm_blocked(on, variant="strict"):
+    """True (default): the register-blocked forms of the GEMM loops; False: the plain loops that define the oracle.  The
+    two run the same chain per output element and give the same bits (tests/test_oracle.py)."""
+    lib(variant).ora_set_gemm_blocked(1 if on else 0)
 
 
 def set_gemm_order(order, s_out=1, variant="strict", plan=None):

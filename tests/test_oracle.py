@@ -259,3 +259,40 @@ def test_mfma_order_twin_matches_its_goldens_bit_exact(pyoracle, synth):
             assert np.array_equal(b[l], g["%s_b%d" % (key, l + 1)]), (key, l)
         assert np.array_equal(o.tensor("scalefactor"), g[key + "_alpha"])
         o.close()
+
+
+@pytest.mark.parametrize("variant", ["strict", "fma"])
+def test_blocked_gemms_equal_the_plain_loops_bit_for_bit(pyoracle, variant):
+    """The oracle's GEMMs run register-blocked (oracle/mlggd_oracle.c, tile_4x16 / gemm_dx_blocked) for speed; the
+    plain loops are the definition.  Same chain per output element => same bits, on ragged shapes (widths that are
+    not multiples of 16 / 8 / 4, 1 and 7 frames), in the documented order, the split twins and the MFMA-order twin."""
+    def run(ls, B, ml, beta, blocked, split=1, order="ref", s_out=1, plan=None):
+        pyoracle.set_gemm_blocked(blocked, variant)
+        pyoracle.set_gemm_split(split, variant)
+        pyoracle.set_gemm_order(order, s_out, variant, plan)
+        try:
+            rng = np.random.default_rng(5)
+            W = [(rng.standard_normal((ls[i], ls[i + 1])) * 0.1).astype(np.float32) for i in range(len(ls) - 1)]
+            b = [(rng.standard_normal(ls[i + 1]) * 0.1).astype(np.float32) for i in range(len(ls) - 1)]
+            net = pyoracle.OracleNet(ls, B, 0.05, 0.9, 1e-4, beta, ml, W, b, variant=variant)
+            for _ in range(3):
+                net.train_bunch(rng.standard_normal((B, ls[0])).astype(np.float32),
+                                rng.standard_normal((B, ls[-1])).astype(np.float32))
+            ws, bs = net.get_weights()
+            res = ws + bs + [net.tensor(n, l) for l in range(1, len(ls)) for n in ("grad_w", "dedx", "y")]
+            net.close()
+            return res
+        finally:
+            pyoracle.set_gemm_blocked(True, variant)
+            pyoracle.set_gemm_split(1, variant)
+            pyoracle.set_gemm_order("ref", 1, variant)
+
+    for ls, B in (([37, 50, 29, 19], 13), ([100, 17, 8, 257], 50), ([283, 96, 40, 31], 7), ([31, 1, 5, 3], 1),
+                  ([33, 129, 65, 9], 128)):
+        for ml, beta in ((0, 2.0), (1, 1.0), (1, 0.9)):
+            for kw in ({}, {"split": 4}, {"split": 7}, {"order": "hip", "s_out": 7},
+                       {"order": "hip", "s_out": 3, "plan": [(1, 1)] * (len(ls) - 1)}):
+                a = run(ls, B, ml, beta, False, **kw)
+                c = run(ls, B, ml, beta, True, **kw)
+                for x, y in zip(a, c):
+                    assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), (ls, B, ml, beta, kw)
