@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""north_star: "per-epoch ML-GGD loss matching the reference to 1e-4 rel" -- over SEVERAL epochs, not one.
+The reference's finetune.pl runs BPtrain_Sigmoid once per epoch over the same corpus (TC/finetune.pl:50-123) and logs the
+CV numbers after each (TC/BPtrain.cc:112-139).  This tool does the same with a one-chunk corpus (102,400 samples = 800
+steps of 128 frames, TC/BP_GPU.cu:170-184) at the shipped topology's width: EPOCHS passes on the GPU, on the CPU oracle,
+and on the oracle's MFMA-order twin (the HIP kernels' own summation order with fused multiply-adds: an equally valid
+reading of cublasSgemm, so its distance to the oracle is what ORDER alone does to the trajectory), and prints after
+every epoch the relative distance of the three logged numbers.  EPOCHS (default 5), CASES (default "1:1.0,1:1.2,0:2.0")."""
+import importlib, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+PKG = "speech-enhancement-based-on-a-maximum-likelihood-criterion_amd"
+pkg = importlib.import_module(PKG); synth = importlib.import_module(PKG + ".synth")
+from oracle import pyoracle
+
+EPOCHS = int(os.environ.get("EPOCHS", "5"))
+CASES = [(int(c.split(":")[0]), float(c.split(":")[1])) for c in os.environ.get("CASES", "1:1.0,1:1.2,0:2.0").split(",")]
+HP = (0.1, 0.9, 1e-5)
+ls, B, n = synth.baseline_layersizes(), 128, 102400
+ws, bs = synth.make_weights(ls)
+inp, targ = synth.make_frames(n, 257, 11)
+cin, ctarg = synth.make_frames(3000, 257, 11, seed=77)
+
+
+def rel(a, b):
+    return abs(a - b) / max(abs(b), 1e-30)
+
+
+for ml, beta in CASES:
+    eng = pkg.BPGpu(synth.DEFAULT_SEED, 0, ls, B, *HP, ws, bs, beta, ml)
+    s_out, plan = eng.out_slabs(), eng.gemm_plan()
+    ora = pyoracle.OracleNet(ls, B, *HP, beta, ml, ws, bs)
+    twin = pyoracle.OracleNet(ls, B, *HP, beta, ml, ws, bs)
+    print("MLflag=%d beta=%.1f, %s, %d steps per epoch; relative distance of (CV sqerr, CV |err|, CV loglik) and of the weights (rel. rms)"
+          % (ml, beta, "-".join(map(str, ls)), n // B), flush=True)
+    for ep in range(1, EPOCHS + 1):
+        t0 = time.time()
+        assert eng.train(inp, targ) == n // B
+        assert ora.train(inp, targ) == n // B
+        pyoracle.set_gemm_order("hip", s_out, plan=plan)
+        try:
+            assert twin.train(inp, targ) == n // B
+            tw = (twin.cv_sqerr(cin, ctarg), twin.cv_abserr(cin, ctarg), twin.cv_loglik(cin, ctarg) if ml else 0.0)
+        finally:
+            pyoracle.set_gemm_order("ref")
+        h = eng.cv_all(cin, ctarg)
+        h = (h[0], h[1], h[2] if ml else 0.0)
+        o = (ora.cv_sqerr(cin, ctarg), ora.cv_abserr(cin, ctarg), ora.cv_loglik(cin, ctarg) if ml else 0.0)
+        w_h, w_o, w_t = eng.returnWeights()[0], ora.get_weights()[0], twin.get_weights()[0]
+        rr = lambda a, b: max(float(np.sqrt(np.mean((x.astype(np.float64) - y) ** 2) / max(np.mean(y.astype(np.float64) ** 2), 1e-300)))
+                              for x, y in zip(a, b))
+        print("  epoch %d: CV sqerr/frame %.4f | HIP vs oracle %.1e %.1e %.1e, weights %.1e | MFMA-order twin vs oracle %.1e %.1e %.1e, weights %.1e"
+              " | HIP vs twin (libm only) %.1e %.1e %.1e, weights %.1e   (%.0f s)"
+              % (ep, o[0] / 3000, rel(h[0], o[0]), rel(h[1], o[1]), rel(h[2], o[2]), rr(w_h, w_o),
+                 rel(tw[0], o[0]), rel(tw[1], o[1]), rel(tw[2], o[2]), rr(w_t, w_o),
+                 rel(h[0], tw[0]), rel(h[1], tw[1]), rel(h[2], tw[2]), rr(w_h, w_t), time.time() - t0), flush=True)
+    eng.close(); ora.close(); twin.close()
