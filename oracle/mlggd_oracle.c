@@ -659,6 +659,36 @@ static void gemm_dw(int B, int K, int N, const float *Y, const float *dEdX, floa
     }
 }
 
+/* The sigmoid's exponential as the HIP kernels evaluate it (csrc/kernels.hip.h exp_det: the SAME statements, IEEE
+ * operations only, no fused multiply-add on either side) -- used by the MFMA-order twin, so that a whole training run
+ * of a net whose loss needs no powf equals the HIP path bit for bit.  The documented-order oracle keeps libm's expf:
+ * which bits CUDA's expf returns no source reading can settle, and both are <= 1-ulp readings of it. */
+__attribute__((optimize("fp-contract=off"))) float ora_exp_det(float x) {
+    if (!(x <= 88.72283f)) return x > 0 ? INFINITY : x; /* overflow; a NaN comes back as it is */
+    if (x < -87.33654f) x = -87.33654f;
+    const float fn = floorf(1.44269504f * x + 0.5f);
+    float r = x - fn * 0.693359375f;
+    r = r - fn * -2.12194440e-4f;
+    const float z = r * r;
+    float p = 1.9875691500e-4f;
+    p = p * r + 1.3981999507e-3f;
+    p = p * r + 8.3334519073e-3f;
+    p = p * r + 4.1665795894e-2f;
+    p = p * r + 1.6666665459e-1f;
+    p = p * r + 5.0000001201e-1f;
+    float y = p * z + r;
+    y = y + 1.0f;
+    const int n = (int)fn, h = n / 2;
+    union { int i; float f; } s1, s2;
+    s1.i = (h + 127) << 23;
+    s2.i = (n - h + 127) << 23;
+    return (y * s1.f) * s2.f;
+}
+__attribute__((optimize("fp-contract=off"))) void ora_exp_det_array(const float *x, float *out, long n, int sigmoid) {
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < n; i++) out[i] = sigmoid ? 1.0f / (1.0f + ora_exp_det(-x[i])) : ora_exp_det(x[i]);
+}
+
 /* ---- forward: BP_GPU.cu:334-369 (train) and :467-509 (cv) ---- */
 void ora_forward(ora_net *net, int n, const float *in) {
     ensure_frames(net, n);
@@ -676,7 +706,7 @@ void ora_forward(ora_net *net, int n, const float *in) {
             float *y = net->layer_y[l];
             const size_t sz = (size_t)n * N;
 #pragma omp parallel for schedule(static)
-            for (size_t i = 0; i < sz; i++) y[i] = 1.0f / (1.0f + expf(-x[i]));
+            for (size_t i = 0; i < sz; i++) y[i] = 1.0f / (1.0f + (g_gemm_order == 1 ? ora_exp_det(-x[i]) : expf(-x[i])));
         } else {
             memcpy(net->out, x, (size_t)n * N * sizeof(float)); /* cudaMemcpy D2D, :367 */
         }

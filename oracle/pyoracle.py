@@ -57,6 +57,7 @@ def lib(variant="strict"):
         L.ora_set_gemm_blocked.argtypes = [C.c_int]
         L.ora_set_gemm_order.argtypes = [C.c_int, C.c_int]
         L.ora_set_gemm_plan.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.ora_exp_det_array.argtypes = [_fp, _fp, C.c_long, C.c_int]
         if "OMP_NUM_THREADS" not in os.environ:
             # a container often sees all host CPUs but may only use a share of them: more threads than
             # that share makes every OpenMP region slower, not faster
@@ -242,6 +243,15 @@ def set_gemm_order(order, s_out=1, variant="strict", plan=None):
     lib(variant).ora_set_gemm_order(1 if order in (1, "hip") else 0, int(s_out))
     for l, (fw, dx) in enumerate(plan or [], start=1):  # BPGpu.gemm_plan(): which GEMM kernel each layer takes
         lib(variant).ora_set_gemm_plan(l, int(fw), int(dx))
+
+
+def exp_det(x, sigmoid=False, variant="strict"):
+    """The HIP kernels' exponential (csrc/kernels.hip.h exp_det, restated: same statements, IEEE operations only), or
+    the sigmoid 1 / (1 + exp_det(-x)) built on it, elementwise."""
+    x, px = _f32(np.ravel(x))
+    out = np.empty_like(x)
+    lib(variant).ora_exp_det_array(px, out.ctypes.data_as(_fp), x.size, 1 if sigmoid else 0)
+    return out
 
 
 def gamma(x):

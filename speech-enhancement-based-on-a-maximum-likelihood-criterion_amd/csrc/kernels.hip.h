@@ -91,6 +91,38 @@ __device__ __forceinline__ void stamp_clk(long long *stamps, int slot, int bid) 
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
 // ---------------------------------------------------------------------------------------
+// The exponential of the sigmoid (kernSigmoid, DevFunc.cu:48: 1 / (1 + exp(-x)); CUDA's expf is a <= 2 ulp function of
+// its own -- which bits it returns no source reading can settle).  This one is written out in IEEE operations ONLY --
+// multiplies, adds, one floor, one float -> int conversion, two exact powers of two; no fused multiply-add (the build
+// has -ffp-contract=off), no hardware transcendental -- so that oracle/mlggd_oracle.c `ora_exp_det` (the SAME
+// statements, compiled by gcc) returns the same bits for every input, and a whole training run of a net whose loss
+// needs no powf (MMSE; ML-GGD with beta = 1, the shipped objective) equals the oracle's MFMA-order twin BIT FOR BIT
+// (tests/test_gpu_mfma_order.py).  Cody-Waite reduction x = n ln2 + r, |r| <= 0.35, degree-6 polynomial (the
+// classic Cephes expf coefficients), scaled by 2^n in two exact steps.  Measured against float64 over 2.3e7 inputs
+// (tests/test_oracle.py): <= 0.96 ulp (ocml's expf: 1 ulp, glibc's: 0.5); the sigmoid built on it <= 2.5 ulp,
+// the same as with glibc's.  Below -87.33 it saturates at 2^-126 (1 + e rounds to 1 there long before).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float exp_det(float x) {
+    if (!(x <= 88.72283f)) return x > 0 ? __builtin_inff() : x;  // overflow; a NaN comes back as it is
+    if (x < -87.33654f) x = -87.33654f;
+    const float fn = __builtin_floorf(1.44269504f * x + 0.5f);
+    float r = x - fn * 0.693359375f;
+    r = r - fn * -2.12194440e-4f;
+    const float z = r * r;
+    float p = 1.9875691500e-4f;
+    p = p * r + 1.3981999507e-3f;
+    p = p * r + 8.3334519073e-3f;
+    p = p * r + 4.1665795894e-2f;
+    p = p * r + 1.6666665459e-1f;
+    p = p * r + 5.0000001201e-1f;
+    float y = p * z + r;
+    y = y + 1.0f;
+    const int n = (int)fn, h = n / 2;
+    return (y * __builtin_bit_cast(float, (h + 127) << 23)) * __builtin_bit_cast(float, (n - h + 127) << 23);
+}
+__device__ __forceinline__ float sigmoid_det(float x) { return 1.0f / (1.0f + exp_det(-x)); }  // kernSigmoid, DevFunc.cu:48
+
+// ---------------------------------------------------------------------------------------
 // Forward GEMM + bias + sigmoid:   X^T[n][b] = sum_k W[k][n] * Yt_in[k][b]  (+ bias[n])
 // replaces kernMultiCopy + cublasSgemm(N,N) + kernSigmoid (BP_GPU.cu:360-364, DevFunc.cu:36-51,
 // 134-149).  One workgroup = one 32(n) x 32(b) output tile; its NW waves split the reduction
@@ -436,10 +468,10 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &A, const int bid, float 
         } else {
             const int n = n0 + row;
             float4 y4;  // kernSigmoid, DevFunc.cu:48
-            y4.x = (n < N) ? 1.0f / (1.0f + expf(-(v4.x + bias_row))) : 0.0f;
-            y4.y = (n < N) ? 1.0f / (1.0f + expf(-(v4.y + bias_row))) : 0.0f;
-            y4.z = (n < N) ? 1.0f / (1.0f + expf(-(v4.z + bias_row))) : 0.0f;
-            y4.w = (n < N) ? 1.0f / (1.0f + expf(-(v4.w + bias_row))) : 0.0f;
+            y4.x = (n < N) ? sigmoid_det(v4.x + bias_row) : 0.0f;
+            y4.y = (n < N) ? sigmoid_det(v4.y + bias_row) : 0.0f;
+            y4.z = (n < N) ? sigmoid_det(v4.z + bias_row) : 0.0f;
+            y4.w = (n < N) ? sigmoid_det(v4.w + bias_row) : 0.0f;
             *reinterpret_cast<float4 *>(&Yt_out[(size_t)n * Bp + b0 + col4]) = y4;
             tileT[col4][row] = y4.x;
             tileT[col4 + 1][row] = y4.y;
@@ -482,7 +514,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &A, const int bid, float 
             if (e < 1024) {
                 const int n = n0 + row;
                 const float x = v[q] + bias_pre[q];
-                const float y = (n < N) ? 1.0f / (1.0f + expf(-x)) : 0.0f;  // kernSigmoid, DevFunc.cu:48
+                const float y = (n < N) ? sigmoid_det(x) : 0.0f;  // kernSigmoid, DevFunc.cu:48
                 Yt_out[(size_t)n * Bp + b0 + col] = y;
                 tileT[col][row] = y;
             }
@@ -1613,13 +1645,14 @@ __global__ __launch_bounds__(256) void k_apply_update(float *__restrict__ Wt, fl
 // Diagnostic (mlggd_debug_math): the device's own libm calls of the loss / activation epilogues applied to an
 // array, so a test can measure in ulps how far ocml's powf / expf sit from the correctly rounded result and from
 // the oracle's glibc -- the only arithmetic of the loss chain that is not IEEE-exact on both sides.
-//   fn 0: powf(x, y)   1: expf(x)   2: 1/(1+expf(-x)) (kernSigmoid, DevFunc.cu:48)   3: x / y
+//   fn 0: powf(x, y)   1: expf(x) (ocml; no kernel uses it any more)   2: sigmoid_det(x), the forward epilogues' sigmoid
+//   3: x / y   4: exp_det(x)
 __global__ __launch_bounds__(256) void k_debug_math(int fn, const float *__restrict__ x, float y, float *__restrict__ out,
                                                     size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float v = x[i];
-    out[i] = fn == 0 ? powf(v, y) : fn == 1 ? expf(v) : fn == 2 ? 1.0f / (1.0f + expf(-v)) : v / y;
+    out[i] = fn == 0 ? powf(v, y) : fn == 1 ? expf(v) : fn == 2 ? sigmoid_det(v) : fn == 4 ? exp_det(v) : v / y;
 }
 
 // keeps one wave busy for `ticks` of the 100 MHz wall clock (bounded: at most `ticks` iterations of a loop whose

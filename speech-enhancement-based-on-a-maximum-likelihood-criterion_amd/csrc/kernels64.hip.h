@@ -189,10 +189,10 @@ __device__ __forceinline__ void fwd64_body(const FwdArgs &A, const int bid, floa
         }
         const float bn = bias_pre[q];
         float4 y4;  // kernSigmoid, DevFunc.cu:48
-        y4.x = (n < N) ? 1.0f / (1.0f + expf(-(v4.x + bn))) : 0.0f;
-        y4.y = (n < N) ? 1.0f / (1.0f + expf(-(v4.y + bn))) : 0.0f;
-        y4.z = (n < N) ? 1.0f / (1.0f + expf(-(v4.z + bn))) : 0.0f;
-        y4.w = (n < N) ? 1.0f / (1.0f + expf(-(v4.w + bn))) : 0.0f;
+        y4.x = (n < N) ? sigmoid_det(v4.x + bn) : 0.0f;
+        y4.y = (n < N) ? sigmoid_det(v4.y + bn) : 0.0f;
+        y4.z = (n < N) ? sigmoid_det(v4.z + bn) : 0.0f;
+        y4.w = (n < N) ? sigmoid_det(v4.w + bn) : 0.0f;
         *reinterpret_cast<float4 *>(&Yt_out[(size_t)n * Bp + b0 + 32 * wn + col4]) = y4;
         T[col4][row] = y4.x;
         T[col4 + 1][row] = y4.y;

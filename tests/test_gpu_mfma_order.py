@@ -104,10 +104,11 @@ def test_dx_equals_the_twin_bitwise(pkg, pyoracle, H, D, B):
     assert bad == 0
 
 
-def test_one_real_step_differs_from_the_twin_only_through_libm(pkg, pyoracle, synth):
-    """2827-2048^3-257, ML-GGD beta 1.2, ordinary data, ONE step: against the twin the first layer's activations are
-    within the sigmoid's 2 ulp (same pre-activation bits, different expf) -- against the documented-order oracle they are
-    not.  States, with numbers, how much of the HIP-vs-oracle distance after one step is order and how much libm."""
+def test_one_real_step_differs_from_the_twin_only_through_powf(pkg, pyoracle, synth):
+    """2827-2048^3-257, ML-GGD beta 1.2, ordinary data, ONE step.  The forward pass -- GEMMs AND sigmoids (exp_det: IEEE
+    operations only, restated in the oracle) -- equals the twin bit for bit: activations of every layer and the output.
+    What is left after the step is the loss chain's powf alone (ocml against glibc, <= 1 ulp each call); against the
+    documented-order oracle the activations already differ.  States how much of the one-step distance is order."""
     ls, B = synth.baseline_layersizes(), 128
     ws, bs = synth.make_weights(ls)
     inp, targ = synth.make_frames(B, 257, 11)
@@ -118,33 +119,58 @@ def test_one_real_step_differs_from_the_twin_only_through_libm(pkg, pyoracle, sy
         assert eng.train(inp, targ) == 1 and twin.train(inp, targ) == 1
         pyoracle.set_gemm_order("ref")
         assert ref.train(inp, targ) == 1
-
-        def ulps(a, b):
-            ia = np.ascontiguousarray(a, np.float32).view(np.int32).astype(np.int64)
-            ib = np.ascontiguousarray(b, np.float32).view(np.int32).astype(np.int64)
-            return np.abs(ia - ib)
-
-        y1 = eng.debug_tensor("y", 1)
-        d_twin, d_ref = ulps(y1, twin.tensor("y", 1, rows=B)), ulps(y1, ref.tensor("y", 1, rows=B))
-        print("layer-1 activations: vs MFMA-order twin max %d ulp (%.1f %% differ) | vs documented order max %d ulp (%.1f %% differ)"
-              % (d_twin.max(), 100 * (d_twin > 0).mean(), d_ref.max(), 100 * (d_ref > 0).mean()))
-        assert d_twin.max() <= 2                       # the sigmoid's libm distance, nothing else
-        assert d_ref.max() > d_twin.max()              # the re-association is the larger part
+        for l in (1, 2, 3):
+            assert np.array_equal(eng.debug_tensor("y", l), twin.tensor("y", l, rows=B)), l
+        assert np.array_equal(eng.debug_tensor("out"), twin.tensor("out", rows=B))
+        assert not np.array_equal(eng.debug_tensor("y", 1), ref.tensor("y", 1, rows=B))   # the documented order: other bits
 
         def rel(a, b):
             return float(np.abs(np.asarray(a, np.float64) - b).max() / np.abs(b).max())
         we, _ = eng.returnWeights()
         wt, _ = twin.get_weights()
         wr, _ = ref.get_weights()
-        out_t, out_r = rel(eng.debug_tensor("out"), twin.tensor("out", rows=B)), rel(eng.debug_tensor("out"), ref.tensor("out", rows=B))
         w_t, w_r = max(rel(a, b) for a, b in zip(we, wt)), max(rel(a, b) for a, b in zip(we, wr))
-        print("after one step: out vs twin %.1e / vs documented order %.1e of max | weights vs twin %.1e / vs documented order %.1e of max|W|"
-              % (out_t, out_r, w_t, w_r))
-        assert out_t <= out_r and w_t <= w_r * 1.5
+        print("after one step (beta 1.2): weights vs twin %.1e (powf only) / vs documented order %.1e of max|W|" % (w_t, w_r))
+        assert w_t <= w_r * 1.5
         twin.close()
     finally:
         pyoracle.set_gemm_order("ref")
         ref.close()
+        eng.close()
+
+
+@pytest.mark.parametrize("ml,beta", [(0, 2.0), (1, 1.0)])
+def test_a_whole_run_equals_the_twin_bit_for_bit_where_the_loss_needs_no_powf(pkg, pyoracle, synth, ml, beta):
+    """MMSE, and ML-GGD with beta = 1 -- the reference's SHIPPED objective (TC/finetune.pl:25-26): the loss chain is
+    IEEE operations in a fixed order (pow_or_self), the GEMMs equal the twin's (above), the sigmoid's exponential is
+    exp_det on both sides, the update is IEEE.  So 60 steps at 2827-2048^3-257 on ordinary data leave EXACTLY the
+    twin's weights, biases, momentum, alpha and CV numbers -- every bit of 14.7 M weights.  Nothing but the summation order
+    and the choice of a <= 1-ulp exponential -- both of which cuBLAS / CUDA's libm leave open -- separates the HIP path
+    from the oracle; any indexing slip, race or stale operand anywhere in a step would show here."""
+    ls, B, steps = synth.baseline_layersizes(), 128, 60
+    ws, bs = synth.make_weights(ls)
+    inp, targ = synth.make_frames(steps * B, 257, 11)
+    cin, ctarg = synth.make_frames(1000, 257, 11, seed=77)
+    eng = pkg.BPGpu(1, 0, ls, B, *HP, ws, bs, beta, ml)
+    try:
+        twin = twin_net(pyoracle, eng, ls, B, *HP, beta, ml, ws, bs)
+        assert eng.train(inp, targ) == steps and twin.train(inp, targ) == steps
+        we, be = eng.returnWeights()
+        wt, bt = twin.get_weights()
+        for l in range(len(we)):
+            assert np.array_equal(we[l], wt[l]), ("weights", l + 1)
+            assert np.array_equal(be[l], bt[l]), ("bias", l + 1)
+            assert np.array_equal(eng.debug_tensor("delta_w", l + 1), twin.tensor("delta_w", l + 1)), ("delta", l + 1)
+        if ml:
+            assert np.array_equal(eng.scalefactor(), twin.tensor("scalefactor"))
+        sq, ab, ll = eng.cv_all(cin, ctarg)
+        assert sq == twin.cv_sqerr(cin, ctarg) and ab == twin.cv_abserr(cin, ctarg)
+        if ml:
+            assert ll == twin.cv_loglik(cin, ctarg)
+        assert any(not np.array_equal(a, b) for a, b in zip(we, ws))          # the net was trained
+        twin.close()
+    finally:
+        pyoracle.set_gemm_order("ref")
         eng.close()
 
 
