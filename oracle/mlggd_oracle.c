@@ -684,6 +684,70 @@ __attribute__((optimize("fp-contract=off"))) float ora_exp_det(float x) {
     s2.i = (n - h + 127) << 23;
     return (y * s1.f) * s2.f;
 }
+/* x^y (x >= 0) as the HIP loss kernels evaluate it (csrc/kernels.hip.h pow_det: the SAME statements -- IEEE double
+ * operations only) -- used by the MFMA-order twin in place of powf, so that the loss chain, too, equals the HIP path bit
+ * for bit at every beta.  The documented-order oracle keeps libm's powf. */
+__attribute__((optimize("fp-contract=off"))) float ora_pow_det(float xf, float yf) {
+    if (xf != xf || yf != yf) return xf + yf;
+    if (yf == 0.0f) return 1.0f;
+    if (xf == 0.0f) return yf > 0 ? 0.0f : INFINITY;
+    if (xf == INFINITY) return yf > 0 ? INFINITY : 0.0f;
+    const double x = (double)xf, y = (double)yf; /* exact; a float denormal is a normal double */
+    union { double d; long long i; } u;
+    u.d = x;
+    const long long bits = u.i;
+    int e = (int)((bits >> 52) & 0x7ff) - 1023;
+    u.i = (bits & 0x000fffffffffffffLL) | 0x3ff0000000000000LL;
+    double m = u.d;                                          /* [1, 2) */
+    if (m > 1.4142135623730951) { m = m * 0.5; e = e + 1; } /* [sqrt(1/2), sqrt 2) */
+    const double s = (m - 1.0) / (m + 1.0), z = s * s;
+    double p = 1.0 / 21.0; /* log m = 2 s (1 + z/3 + z^2/5 + ...), |s| <= 0.1716: z^10 / 21 < 2e-17 */
+    p = p * z + 1.0 / 19.0;
+    p = p * z + 1.0 / 17.0;
+    p = p * z + 1.0 / 15.0;
+    p = p * z + 1.0 / 13.0;
+    p = p * z + 1.0 / 11.0;
+    p = p * z + 1.0 / 9.0;
+    p = p * z + 1.0 / 7.0;
+    p = p * z + 1.0 / 5.0;
+    p = p * z + 1.0 / 3.0;
+    p = p * z + 1.0;
+    const double lg = (2.0 * s) * p + (double)e * 0.6931471805599453;
+    const double t = y * lg;
+    if (t > 89.0) return INFINITY;
+    if (t < -104.0) return 0.0f;
+    const double fn = floor(t * 1.4426950408889634 + 0.5);
+    double r = t - fn * 0.6931471803691238; /* ln 2, high part (its trailing bits are zero: fn * high is exact) */
+    r = r - fn * 1.9082149292705877e-10;    /* ln 2, low part */
+    double q = 1.0 / 6227020800.0;          /* 1 / 13! */
+    q = q * r + 1.0 / 479001600.0;
+    q = q * r + 1.0 / 39916800.0;
+    q = q * r + 1.0 / 3628800.0;
+    q = q * r + 1.0 / 362880.0;
+    q = q * r + 1.0 / 40320.0;
+    q = q * r + 1.0 / 5040.0;
+    q = q * r + 1.0 / 720.0;
+    q = q * r + 1.0 / 120.0;
+    q = q * r + 1.0 / 24.0;
+    q = q * r + 1.0 / 6.0;
+    q = q * r + 0.5;
+    q = q * r + 1.0;
+    q = q * r + 1.0;
+    const int n = (int)fn; /* in [-151, 129]: 2^n is a normal double */
+    u.i = (long long)(n + 1023) << 52;
+    return (float)(q * u.d);
+}
+void ora_pow_det_array(const float *x, float y, float *out, long n) {
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < n; i++) out[i] = ora_pow_det(x[i], y);
+}
+/* the loss chain's pow: libm's powf in the documented-order oracle; in the MFMA-order twin the HIP kernels' pow_or_self
+ * (x for y = 1, 1 for y = 0 -- what powf returns there as well -- and pow_det otherwise) */
+static float lpow(float x, float y) {
+    if (g_gemm_order != 1) return powf(x, y);
+    return y == 1.0f ? x : y == 0.0f ? 1.0f : ora_pow_det(x, y);
+}
+
 __attribute__((optimize("fp-contract=off"))) void ora_exp_det_array(const float *x, float *out, long n, int sigmoid) {
 #pragma omp parallel for schedule(static)
     for (long i = 0; i < n; i++) out[i] = sigmoid ? 1.0f / (1.0f + ora_exp_det(-x[i])) : ora_exp_det(x[i]);
@@ -724,7 +788,7 @@ void ora_loss_colsum(ora_net *net, int n, const float *targ, float *colsum) {
             const size_t i = (size_t)b * D + d;
             net->realerror[i] = net->out[i] - targ[i];
             net->errorabsolute[i] = fabsf(net->realerror[i]);
-            net->errorabsolute2[i] = powf(net->errorabsolute[i], beta);
+            net->errorabsolute2[i] = lpow(net->errorabsolute[i], beta);
         }
     for (int d = 0; d < D; d++) {
         float s = net->errorabsolute2[d];
@@ -745,9 +809,9 @@ void ora_loss_grad(ora_net *net, int n, int n_global, const float *targ, const f
             const size_t i = (size_t)b * D + d;
             const float o = net->out[i], t = targ[i];
             float g;
-            if (o > t) g = beta * powf(o - t, beta - 1);
+            if (o > t) g = beta * lpow(o - t, beta - 1);
             else if (o == t) g = 0;
-            else g = -beta * powf(t - o, beta - 1);
+            else g = -beta * lpow(t - o, beta - 1);
             dedx[i] = g;
         }
     /* kernVecMulNum, DevFunc.cu:287-293 <- :409 */
@@ -762,7 +826,7 @@ void ora_loss_grad(ora_net *net, int n, int n_global, const float *targ, const f
         for (int d = 0; d < D; d++) {
             net->vec1[d] = colsum_global[d] / nf;
             net->vec2[d] = net->vec1[d] * beta;
-            net->scalefactor[d] = powf(net->vec2[d], ppp);
+            net->scalefactor[d] = lpow(net->vec2[d], ppp);
         }
         /* kernfunc2, DevFunc.cu:468-489 <- :422 */
         for (int b = 0; b < n; b++)
@@ -770,9 +834,9 @@ void ora_loss_grad(ora_net *net, int n, int n_global, const float *targ, const f
                 const size_t i = (size_t)b * D + d;
                 const float e = net->realerror[i];
                 float g;
-                if (e > 0) g = powf(e, beta - 1.0f) * beta / powf(net->scalefactor[d], beta);
+                if (e > 0) g = lpow(e, beta - 1.0f) * beta / lpow(net->scalefactor[d], beta);
                 else if (e == 0) g = 0;
-                else g = -powf(-e, beta - 1.0f) * beta / powf(net->scalefactor[d], beta);
+                else g = -lpow(-e, beta - 1.0f) * beta / lpow(net->scalefactor[d], beta);
                 net->newobj[i] = g;
             }
         /* kernVecMulNum <- :423 */

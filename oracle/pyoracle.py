@@ -58,6 +58,7 @@ def lib(variant="strict"):
         L.ora_set_gemm_order.argtypes = [C.c_int, C.c_int]
         L.ora_set_gemm_plan.argtypes = [C.c_int, C.c_int, C.c_int]
         L.ora_exp_det_array.argtypes = [_fp, _fp, C.c_long, C.c_int]
+        L.ora_pow_det_array.argtypes = [_fp, C.c_float, _fp, C.c_long]
         if "OMP_NUM_THREADS" not in os.environ:
             # a container often sees all host CPUs but may only use a share of them: more threads than
             # that share makes every OpenMP region slower, not faster
@@ -251,6 +252,14 @@ def exp_det(x, sigmoid=False, variant="strict"):
     x, px = _f32(np.ravel(x))
     out = np.empty_like(x)
     lib(variant).ora_exp_det_array(px, out.ctypes.data_as(_fp), x.size, 1 if sigmoid else 0)
+    return out
+
+
+def pow_det(x, y, variant="strict"):
+    """x ** y (x >= 0) as the HIP loss kernels evaluate it (csrc/kernels.hip.h pow_det, restated), elementwise."""
+    x, px = _f32(np.ravel(x))
+    out = np.empty_like(x)
+    lib(variant).ora_pow_det_array(px, float(np.float32(y)), out.ctypes.data_as(_fp), x.size)
     return out
 
 

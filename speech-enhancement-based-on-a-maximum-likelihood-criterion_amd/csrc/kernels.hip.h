@@ -122,6 +122,61 @@ __device__ __forceinline__ float exp_det(float x) {
 }
 __device__ __forceinline__ float sigmoid_det(float x) { return 1.0f / (1.0f + exp_det(-x)); }  // kernSigmoid, DevFunc.cu:48
 
+// The power of the loss chain (pow_or_self below; kernindex2 / kernfunc2, DevFunc.cu:219-227,468-489): pow_det, x^y (x >= 0) as exp(y log x) in IEEE DOUBLE operations only -- adds, multiplies,
+// one division, one floor, exact bit manipulation; no fused multiply-add, no libm, no hardware transcendental -- so that
+// oracle/mlggd_oracle.c `ora_pow_det` (the SAME statements, compiled by gcc) returns the same bits for every argument and
+// the loss chain equals the oracle's MFMA-order twin bit for bit at EVERY beta, like the GEMMs and the sigmoid
+// (tests/test_gpu_mfma_order.py: whole training runs).  log m = 2 atanh((m-1)/(m+1)) by its series on [sqrt(1/2), sqrt 2),
+// exp by Cody-Waite reduction and its Taylor polynomial of degree 13: ~1e-15 relative in double, so the float result is
+// the CORRECTLY ROUNDED power in all but 5 of a million cases (measured against 80-bit powl over 2.2e7 arguments,
+// tests/test_oracle.py; glibc's powf: 640 of a million, ocml's: 110,000-230,000).  CUDA's powf is a 2-ulp function of its own.
+__device__ __forceinline__ float pow_det(float xf, float yf) {
+    if (xf != xf || yf != yf) return xf + yf;
+    if (yf == 0.0f) return 1.0f;
+    if (xf == 0.0f) return yf > 0 ? 0.0f : __builtin_inff();
+    if (xf == __builtin_inff()) return yf > 0 ? __builtin_inff() : 0.0f;
+    const double x = (double)xf, y = (double)yf;  // exact; a float denormal is a normal double
+    const long long bits = __builtin_bit_cast(long long, x);
+    int e = (int)((bits >> 52) & 0x7ff) - 1023;
+    double m = __builtin_bit_cast(double, (bits & 0x000fffffffffffffLL) | 0x3ff0000000000000LL);  // [1, 2)
+    if (m > 1.4142135623730951) { m = m * 0.5; e = e + 1; }                                        // [sqrt(1/2), sqrt 2)
+    const double s = (m - 1.0) / (m + 1.0), z = s * s;
+    double p = 1.0 / 21.0;  // log m = 2 s (1 + z/3 + z^2/5 + ...), |s| <= 0.1716: z^10 / 21 < 2e-17
+    p = p * z + 1.0 / 19.0;
+    p = p * z + 1.0 / 17.0;
+    p = p * z + 1.0 / 15.0;
+    p = p * z + 1.0 / 13.0;
+    p = p * z + 1.0 / 11.0;
+    p = p * z + 1.0 / 9.0;
+    p = p * z + 1.0 / 7.0;
+    p = p * z + 1.0 / 5.0;
+    p = p * z + 1.0 / 3.0;
+    p = p * z + 1.0;
+    const double lg = (2.0 * s) * p + (double)e * 0.6931471805599453;
+    const double t = y * lg;
+    if (t > 89.0) return __builtin_inff();
+    if (t < -104.0) return 0.0f;
+    const double fn = __builtin_floor(t * 1.4426950408889634 + 0.5);
+    double r = t - fn * 0.6931471803691238;  // ln 2, high part (its trailing bits are zero: fn * high is exact)
+    r = r - fn * 1.9082149292705877e-10;     // ln 2, low part
+    double q = 1.0 / 6227020800.0;           // 1 / 13!
+    q = q * r + 1.0 / 479001600.0;
+    q = q * r + 1.0 / 39916800.0;
+    q = q * r + 1.0 / 3628800.0;
+    q = q * r + 1.0 / 362880.0;
+    q = q * r + 1.0 / 40320.0;
+    q = q * r + 1.0 / 5040.0;
+    q = q * r + 1.0 / 720.0;
+    q = q * r + 1.0 / 120.0;
+    q = q * r + 1.0 / 24.0;
+    q = q * r + 1.0 / 6.0;
+    q = q * r + 0.5;
+    q = q * r + 1.0;
+    q = q * r + 1.0;
+    const int n = (int)fn;  // in [-151, 129]: 2^n is a normal double
+    return (float)(q * __builtin_bit_cast(double, (long long)(n + 1023) << 52));
+}
+
 // ---------------------------------------------------------------------------------------
 // Forward GEMM + bias + sigmoid:   X^T[n][b] = sum_k W[k][n] * Yt_in[k][b]  (+ bias[n])
 // replaces kernMultiCopy + cublasSgemm(N,N) + kernSigmoid (BP_GPU.cu:360-364, DevFunc.cu:36-51,
@@ -1646,13 +1701,13 @@ __global__ __launch_bounds__(256) void k_apply_update(float *__restrict__ Wt, fl
 // array, so a test can measure in ulps how far ocml's powf / expf sit from the correctly rounded result and from
 // the oracle's glibc -- the only arithmetic of the loss chain that is not IEEE-exact on both sides.
 //   fn 0: powf(x, y)   1: expf(x) (ocml; no kernel uses it any more)   2: sigmoid_det(x), the forward epilogues' sigmoid
-//   3: x / y   4: exp_det(x)
+//   3: x / y   4: exp_det(x)   5: pow_det(x, y), the loss chain's power
 __global__ __launch_bounds__(256) void k_debug_math(int fn, const float *__restrict__ x, float y, float *__restrict__ out,
                                                     size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float v = x[i];
-    out[i] = fn == 0 ? powf(v, y) : fn == 1 ? expf(v) : fn == 2 ? sigmoid_det(v) : fn == 4 ? exp_det(v) : v / y;
+    out[i] = fn == 0 ? powf(v, y) : fn == 1 ? expf(v) : fn == 2 ? sigmoid_det(v) : fn == 4 ? exp_det(v) : fn == 5 ? pow_det(v, y) : v / y;
 }
 
 // keeps one wave busy for `ticks` of the 100 MHz wall clock (bounded: at most `ticks` iterations of a loop whose
@@ -1801,7 +1856,8 @@ __device__ __forceinline__ float slab_sum(const float *__restrict__ slab, size_t
 // in tests/test_gpu_loss_ulps.py.
 // ---------------------------------------------------------------------------------------
 constexpr int LOSS_DT = 8;  // output units per loss workgroup
-__device__ __forceinline__ float pow_or_self(float x, float p) { return p == 1.0f ? x : p == 0.0f ? 1.0f : powf(x, p); }
+// For every other exponent: pow_det (defined beside exp_det above).
+__device__ __forceinline__ float pow_or_self(float x, float p) { return p == 1.0f ? x : p == 0.0f ? 1.0f : pow_det(x, p); }
 
 // Phase A:   out = bias + sum_s slab;  e = out - targ;  p = |e|^beta
 // kernerror, kernabsolutevalus, kernindex2 (DevFunc.cu:399-409,186-191,219-227 <- BP_GPU.cu:413-415).

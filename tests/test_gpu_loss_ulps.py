@@ -74,6 +74,21 @@ def test_device_powf_and_expf_in_ulps(pkg, pyoracle, synth):
         print("powf(x, %.1f): device vs the exact result max %d ulp (%.1f %% differ); glibc exact"
               % (y, d.max(), 100 * (d > 0).mean()))
         assert d.max() <= 2
+    # pow_det (kernels.hip.h): what the loss kernels call since r04 instead of ocml's powf -- IEEE double operations only,
+    # restated statement for statement in the oracle (ora_pow_det): same bits on both sides for every argument, and the
+    # correctly rounded power in all but a few of a million cases
+    xs = np.concatenate([x, [0.0, 1e-45, 1e-38, 1.0, 3e38, np.inf]]).astype(np.float32)
+    for y in (0.9, 1.2, 0.9 - 1.0, 1.2 - 1.0, 1.0 / 0.9, 1.0 / 1.2, 2.0, 0.5, -1.0, 0.0, 1.0):
+        y32 = np.float32(y)
+        dev = eng.debug_math("pow_det", xs, y32)
+        assert np.array_equal(dev.view(np.uint32), pyoracle.pow_det(xs, y32).view(np.uint32)), y
+        with np.errstate(divide="ignore", over="ignore"):
+            exact = np.power(xs[:-5].astype(np.float64), np.float64(y32)).astype(np.float32)
+        d = ulp_dist(dev[:-5], exact)
+        assert d.max() <= 1, (y, d.max())
+        if y in (0.9, 1.2, 2.0):
+            print("pow_det(x, %.1f): device = CPU restatement in every bit; vs float64 pow rounded: max %d ulp (%.4f %% differ)"
+                  % (y, d.max(), 100 * (d > 0).mean()))
     for r in report:
         print("powf(x, %+.4f): device vs exact max %d ulp (%.1f %% differ) | glibc vs exact max %d ulp (%.1f %%) | "
               "device vs glibc max %d ulp (%.1f %% differ)" % (r[0], r[1], 100 * r[2], r[3], 100 * r[4], r[5], 100 * r[6]))
@@ -152,5 +167,14 @@ def test_loss_chain_on_an_exactly_representable_output_layer(pkg, pyoracle, beta
         assert da.max() <= bound_a, (int(da.max()), bound_a)
         assert dg.max() <= bound_g, (int(dg.max()), bound_g)
         assert dg.mean() <= 1.5
+    # against the oracle's MFMA-order twin (the same IEEE-only pow_det on both sides) the chain is the same bits at EVERY beta
+    pyoracle.set_gemm_order("hip", eng.out_slabs(), plan=eng.gemm_plan())
+    try:
+        tw = pyoracle.OracleNet(ls, B, *HP, beta, 1, [W], [b])
+        assert tw.train(x, targ) == 1
+        assert np.array_equal(g_e, tw.tensor("dedx", 1, rows=B)) and np.array_equal(a_e, tw.tensor("scalefactor"))
+        tw.close()
+    finally:
+        pyoracle.set_gemm_order("ref")
     eng.close()
     ora.close()
