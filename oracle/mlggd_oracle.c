@@ -665,7 +665,7 @@ static void gemm_dw(int B, int K, int N, const float *Y, const float *dEdX, floa
  * which bits CUDA's expf returns no source reading can settle, and both are <= 1-ulp readings of it. */
 __attribute__((optimize("fp-contract=off"))) float ora_exp_det(float x) {
     if (!(x <= 88.72283f)) return x > 0 ? INFINITY : x; /* overflow; a NaN comes back as it is */
-    if (x < -87.33654f) x = -87.33654f;
+    if (x < -85.5f) x = -85.5f; /* n >= -123 below: y * 2^(n-1) stays a normal number */
     const float fn = floorf(1.44269504f * x + 0.5f);
     float r = x - fn * 0.693359375f;
     r = r - fn * -2.12194440e-4f;
@@ -678,11 +678,9 @@ __attribute__((optimize("fp-contract=off"))) float ora_exp_det(float x) {
     p = p * r + 5.0000001201e-1f;
     float y = p * z + r;
     y = y + 1.0f;
-    const int n = (int)fn, h = n / 2;
-    union { int i; float f; } s1, s2;
-    s1.i = (h + 127) << 23;
-    s2.i = (n - h + 127) << 23;
-    return (y * s1.f) * s2.f;
+    union { int i; float f; } s1;
+    s1.i = ((int)fn + 126) << 23;
+    return (y * s1.f) * 2.0f; /* 2^n as 2^(n-1) * 2: n = 128 has no float of its own */
 }
 /* x^y (x >= 0) as the HIP loss kernels evaluate it (csrc/kernels.hip.h pow_det: the SAME statements -- IEEE double
  * operations only) -- used by the MFMA-order twin in place of powf, so that the loss chain, too, equals the HIP path bit

@@ -98,10 +98,10 @@ def test_device_powf_and_expf_in_ulps(pkg, pyoracle, synth):
     # what lets whole training runs equal the oracle's MFMA-order twin (tests/test_gpu_mfma_order.py) -- and how far that
     # exponential sits from the correctly rounded one is measured, not assumed
     v = np.concatenate([rng.normal(0, 4, 100000), rng.uniform(-100, 100, 20000),
-                        [0.0, -0.0, 88.72283, 88.8, -87.33654, -87.4, -200.0, 200.0, 1e-30, -1e-30]]).astype(np.float32)
+                        [0.0, -0.0, 88.72283, 88.8, -85.5, -87.4, -200.0, 200.0, 1e-30, -1e-30]]).astype(np.float32)
     for fn, sig in (("exp_det", False), ("sigmoid", True)):
         assert np.array_equal(eng.debug_math(fn, v).view(np.uint32), pyoracle.exp_det(v, sigmoid=sig).view(np.uint32)), fn
-    inr = np.abs(v) < 87.0
+    inr = np.abs(v) < 85.5
     d = ulp_dist(eng.debug_math("exp_det", v)[inr], np.exp(v[inr].astype(np.float64)).astype(np.float32))
     d_ocml = ulp_dist(eng.debug_math("expf", v)[inr], np.exp(v[inr].astype(np.float64)).astype(np.float32))
     print("exp_det: device vs correctly rounded max %d ulp (%.1f %% differ) | ocml expf max %d ulp (%.1f %% differ)"
