@@ -207,10 +207,11 @@ int mlggd_debug_out_slabs(mlggd_handle h, int *slabs);
  * kernels for large minibatches (k_fwd64 / k_dx64: one chain per output element).  The MFMA-order twin restates it. */
 int mlggd_debug_gemm_plan(mlggd_handle h, int layer, int *fwd_waves, int *dx_waves);
 
-/* Diagnostic: out[i] = fn(x[i], y) evaluated on the device with the libm calls the kernels themselves use -- fn "powf"
- * (kernindex2 / kernfunc2 / kernSubClean2, DevFunc.cu:219-227,468-489,376-398), "expf", "sigmoid" = 1/(1+expf(-x))
- * (kernSigmoid, DevFunc.cu:36-51), "div" = x / y.  Parity tests use it to state, in ulps, how far the device's libm
- * sits from the oracle's: the one part of the loss chain that is not bit-exact IEEE arithmetic on both sides. */
+/* Diagnostic: out[i] = fn(x[i], y) evaluated on the device -- fn "pow_det" (the loss chain's power: kernindex2 / kernfunc2 /
+ * kernSubClean2, DevFunc.cu:219-227,468-489,376-398), "exp_det", "sigmoid" = 1 / (1 + exp_det(-x)) (kernSigmoid,
+ * DevFunc.cu:36-51): what the kernels themselves evaluate, IEEE operations only, restated in the oracle's MFMA-order twin --
+ * the parity tests require the SAME BITS on both sides for every argument; "div" = x / y (IEEE); and, for the record only,
+ * ocml's own "powf" and "expf", which no kernel calls: how far they sit from the correctly rounded values, in ulps. */
 int mlggd_debug_math(mlggd_handle h, const char *fn, const float *x, float y, float *out, size_t n);
 
 /* Diagnostic (not part of the reference surface): in-kernel phase stamps of the NEXT launch of
