@@ -720,14 +720,20 @@ def rank_main(args):
         cin, ctarg = synth.make_frames(1000, 257, 11, seed=77)
 
         def scores(o_or_eng, ml_, is_engine):
+            import zlib
             if is_engine:
                 sq, ab, ll = o_or_eng.cv_all(cin, ctarg)
                 al = o_or_eng.scalefactor() if ml_ else None
+                w, b_ = o_or_eng.returnWeights()
             else:
                 sq, ab = o_or_eng.cv_sqerr(cin, ctarg), o_or_eng.cv_abserr(cin, ctarg)
                 ll = o_or_eng.cv_loglik(cin, ctarg) if ml_ else 0.0
                 al = o_or_eng.tensor("scalefactor").copy() if ml_ else None
-            return sq, ab, ll, al
+                w, b_ = o_or_eng.get_weights()
+            crc = 0
+            for a in list(w) + list(b_):  # every bit of the trained net
+                crc = zlib.crc32(np.ascontiguousarray(a, np.float32).tobytes(), crc)
+            return sq, ab, ll, al, crc
 
         def delta(a, r, ml_):
             d = {"cv_sqerr_rel": abs(a[0] - r[0]) / abs(r[0]), "cv_abserr_rel": abs(a[1] - r[1]) / abs(r[1])}
@@ -771,7 +777,7 @@ def rank_main(args):
             """HIP vs oracle after the same steps, next to the YARDSTICKS: the same oracle in other, equally valid
             arithmetic -- forward / dX reductions as 4 resp. 7 contiguous partial sums (what any split-K GEMM does; cuBLAS
             leaves the order open), the build with FMA contraction on (nvcc's default), and the MFMA-order twin (the HIP
-            kernels' exact summation order on the CPU: what is left between it and the HIP path is libm alone)."""
+            kernels' exact summation order, exponential and power on the CPU: the HIP path equals it in every bit)."""
             hip, s_out = engine_after(ml_, beta_, n_)
             ref = ref if ref is not None else oracle_after(ml_, beta_, n_)
             leg = {"steps": n_ + 2, "loss_vs_oracle": delta(hip, ref, ml_)}
@@ -787,9 +793,11 @@ def rank_main(args):
                 tw = oracle_after(ml_, beta_, n_, **kw)
                 yard[name] = delta(tw, ref, ml_)
                 if name == "mfma_order":
-                    # same summation order on both sides (the GEMMs are bit-identical, tests/test_gpu_mfma_order.py):
-                    # what separates the HIP path from THIS twin is libm alone (expf in the sigmoid, powf in the loss)
+                    # the HIP kernels' summation order, exponential and power restated on the CPU: the HIP path must
+                    # equal THIS twin in every bit (tests/test_gpu_mfma_order.py) -- a CRC over all weights and biases
+                    # says so here, and the distances are 0
                     leg["hip_vs_mfma_order_twin"] = delta(hip, tw, ml_)
+                    leg["hip_equals_mfma_order_twin_bitwise"] = bool(hip[4] == tw[4])
             leg["oracle_twins_vs_oracle"] = yard
             if yard:
                 worst = {k: max(y[k] for y in yard.values()) for k in leg["loss_vs_oracle"]}
@@ -803,7 +811,8 @@ def rank_main(args):
         out["loss_vs_oracle"] = dict(head_leg["loss_vs_oracle"], steps=head_leg["steps"])
         out["loss_vs_oracle_twins"] = {"oracle_twins_vs_oracle": head_leg["oracle_twins_vs_oracle"],
                                        "hip_over_largest_twin": head_leg.get("hip_over_largest_twin"),
-                                       "hip_vs_mfma_order_twin": head_leg.get("hip_vs_mfma_order_twin")}
+                                       "hip_vs_mfma_order_twin": head_leg.get("hip_vs_mfma_order_twin"),
+                                       "hip_equals_mfma_order_twin_bitwise": head_leg.get("hip_equals_mfma_order_twin_bitwise")}
         if "ml_ggd" in out:
             n_ml = min(n, 150)
             for key, b_, what in (("ml_ggd", 1.2, None),
@@ -817,7 +826,8 @@ def rank_main(args):
                 tgt["loss_vs_oracle"] = dict(leg["loss_vs_oracle"], steps=leg["steps"])
                 tgt["oracle_twins_vs_oracle"] = leg["oracle_twins_vs_oracle"]
                 tgt["hip_over_largest_twin"] = leg.get("hip_over_largest_twin")
-                tgt["hip_vs_mfma_order_twin"] = leg.get("hip_vs_mfma_order_twin")  # libm only (same summation order)
+                tgt["hip_vs_mfma_order_twin"] = leg.get("hip_vs_mfma_order_twin")
+                tgt["hip_equals_mfma_order_twin_bitwise"] = leg.get("hip_equals_mfma_order_twin_bitwise")
     # cpu_baseline is part of the line's contract at N = 1: it runs whatever the budget says (bounded: ~2 x --cpu-seconds);
     # its parity legs check the budget themselves
     if rank == 0 and world == 1 and not dp and not args.no_cpu_baseline:
