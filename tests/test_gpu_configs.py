@@ -103,6 +103,33 @@ def test_config4_eight_ranks_at_the_real_shape(pkg, pyoracle, synth, mode):
     ora.close()
 
 
+@pytest.mark.parametrize("mode", ["gather", "shard", "shard_a2a"])
+def test_eight_ranks_equal_the_twin_at_bunchsize_1024_in_every_bit(pkg, pyoracle, synth, mode):
+    """The data-parallel contract, sharpened: with the factor exchanges the weight gradient is ONE chain per weight over
+    the frames of the global minibatch in their order (rank 0's rows, rank 1's, ...), everything before it is per frame,
+    and the MMSE loss needs no cross-rank statistic -- so 8 ranks x 128 frames at 2827-2048^3-257 must leave exactly
+    the bits of the oracle's MFMA-order twin run with bunchsize 1024 on the same rows (the gradient all-reduce sums
+    per-rank partial chains instead and is held to the tolerance above)."""
+    ls, B, world, steps = synth.baseline_layersizes(), 128, 8, 3
+    ws, bs = synth.make_weights(ls, seed=41)
+    inp, targ = synth.make_frames(steps * world * B, 257, 11, seed=43)
+    eng = pkg.BPGpu(1, 0, ls, B, *HP, ws, bs, 2.0, 0)
+    eng.fake_world(world, sharded=mode == "shard", a2a=mode == "shard_a2a")
+    pyoracle.set_gemm_order("hip", eng.out_slabs(), plan=eng.gemm_plan())
+    try:
+        twin = pyoracle.OracleNet(ls, world * B, *HP, 2.0, 0, ws, bs)
+        assert eng.train(inp, targ) == steps and twin.train(inp, targ) == steps
+        we, be = eng.returnWeights()
+        wt, bt = twin.get_weights()
+        for l in range(len(we)):
+            assert np.array_equal(we[l], wt[l]), ("weights", l + 1)
+            assert np.array_equal(be[l], bt[l]), ("bias", l + 1)
+        twin.close()
+    finally:
+        pyoracle.set_gemm_order("ref")
+        eng.close()
+
+
 def test_config5_eight_ranks_take_the_allreduce_exchange(pkg, pyoracle, synth):
     """BASELINE config 5 in its 8-GPU form: 2827-4096^6-257, 512 frames per rank, ML-GGD beta 1.2, eight ranks
     emulated on one GPU against the oracle with bunchsize 4096 on the same rows.  At 8 x 512 frames the
