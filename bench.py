@@ -612,6 +612,21 @@ def rank_main(args):
             wo, _ = ora.get_weights()
             res["weights_relmax"] = max(float(np.abs(a_ - o_).max() / np.abs(o_).max()) for a_, o_ in zip(w_, wo))
             ora.close()
+            if not ml_ and e2.dp_mode() >= 2 and hasattr(e2, "out_slabs"):
+                # factor exchanges + MMSE: the weight gradient is one chain per weight over the frames of the global
+                # minibatch in their order and no statistic crosses the ranks, so the N replicas must hold exactly the bits
+                # of the oracle's MFMA-order twin at bunchsize world x B (tests/test_gpu_configs.py, 8 emulated ranks)
+                pyoracle.set_gemm_order("hip", e2.out_slabs(), plan=e2.gemm_plan())
+                try:
+                    tw = pyoracle.OracleNet(ls, world * B, 0.1, 0.9, 1e-5, beta_, ml_, ws, bs)
+                    for t in range(kpar):
+                        tw.train_bunch(np.concatenate([x[t * B:(t + 1) * B] for x, _ in rows]),
+                                       np.concatenate([y[t * B:(t + 1) * B] for _, y in rows]))
+                    wt, bt = tw.get_weights()
+                    tw.close()
+                finally:
+                    pyoracle.set_gemm_order("ref")
+                res["hip_equals_mfma_order_twin_bitwise"] = all(np.array_equal(a_, t_) for a_, t_ in zip(list(w_) + list(b_), list(wt) + list(bt)))
             res = {k: (float("%.2e" % v) if isinstance(v, float) else v) for k, v in res.items()}
         e2.close()
         wd.enter("%s: barrier after the oracle" % label, 900, "gloo barrier (rank 0 is running the CPU oracle)")

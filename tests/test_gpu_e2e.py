@@ -628,3 +628,4 @@ def test_bench_rehearses_the_data_parallel_path_on_one_gpu():
         assert leg["replicas_identical"] is True and leg["steps"] == 5 and leg["oracle_bunchsize"] == 128
         assert leg["cv_sqerr_rel"] < 1e-4 and leg["cv_abserr_rel"] < 1e-4 and leg["weights_relmax"] < 2e-5
     assert d["ml_ggd"]["loss_vs_oracle"]["cv_loglik_rel"] < 1e-4
+    assert d["loss_vs_oracle"]["hip_equals_mfma_order_twin_bitwise"] is True   # MMSE through the factor exchange: the twin's bits
