@@ -663,9 +663,10 @@ static void gemm_dw(int B, int K, int N, const float *Y, const float *dEdX, floa
  * operations only, no fused multiply-add on either side) -- used by the MFMA-order twin, so that a whole training run
  * of a net whose loss needs no powf equals the HIP path bit for bit.  The documented-order oracle keeps libm's expf:
  * which bits CUDA's expf returns no source reading can settle, and both are <= 1-ulp readings of it. */
-__attribute__((optimize("fp-contract=off"))) float ora_exp_det(float x) {
-    if (!(x <= 88.72283f)) return x > 0 ? INFINITY : x; /* overflow; a NaN comes back as it is */
-    if (x < -85.5f) x = -85.5f; /* n >= -123 below: y * 2^(n-1) stays a normal number */
+__attribute__((optimize("fp-contract=off"))) float ora_exp_det(float x0) {
+    float x = x0 < -85.5f ? -85.5f : x0; /* n >= -123 below: y * 2^(n-1) stays a normal number */
+    x = x > 88.72283f ? 88.72283f : x;   /* beyond it the result is +inf (selected at the end) */
+    x = x0 != x0 ? 0.0f : x;             /* a NaN comes back as it is (selected at the end) */
     const float fn = floorf(1.44269504f * x + 0.5f);
     float r = x - fn * 0.693359375f;
     r = r - fn * -2.12194440e-4f;
@@ -680,7 +681,8 @@ __attribute__((optimize("fp-contract=off"))) float ora_exp_det(float x) {
     y = y + 1.0f;
     union { int i; float f; } s1;
     s1.i = ((int)fn + 126) << 23;
-    return (y * s1.f) * 2.0f; /* 2^n as 2^(n-1) * 2: n = 128 has no float of its own */
+    const float e = (y * s1.f) * 2.0f; /* 2^n as 2^(n-1) * 2: n = 128 has no float of its own */
+    return x0 != x0 ? x0 : x0 > 88.72283f ? INFINITY : e;
 }
 /* x^y (x >= 0) as the HIP loss kernels evaluate it (csrc/kernels.hip.h pow_det: the SAME statements -- IEEE double
  * operations only) -- used by the MFMA-order twin in place of powf, so that the loss chain, too, equals the HIP path bit

@@ -102,9 +102,11 @@ __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane
 // (tests/test_oracle.py): <= 0.96 ulp (ocml's expf: 1 ulp, glibc's: 0.5); the sigmoid built on it <= 2.5 ulp,
 // the same as with glibc's.  Below -85.5 it saturates at 7.4e-38 (1 + e rounds to 1 there long before).
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ float exp_det(float x) {
-    if (!(x <= 88.72283f)) return x > 0 ? __builtin_inff() : x;  // overflow; a NaN comes back as it is
-    if (x < -85.5f) x = -85.5f;  // n >= -123 below: y * 2^(n-1) stays a normal number
+__device__ __forceinline__ float exp_det(float x0) {
+    // (selects, not branches: the four elements of a thread stay one straight instruction stream -- 1 us per step)
+    float x = x0 < -85.5f ? -85.5f : x0;  // n >= -123 below: y * 2^(n-1) stays a normal number
+    x = x > 88.72283f ? 88.72283f : x;    // beyond it the result is +inf (selected at the end)
+    x = x0 != x0 ? 0.0f : x;              // a NaN comes back as it is (selected at the end)
     const float fn = __builtin_floorf(1.44269504f * x + 0.5f);
     float r = x - fn * 0.693359375f;
     r = r - fn * -2.12194440e-4f;
@@ -117,7 +119,8 @@ __device__ __forceinline__ float exp_det(float x) {
     p = p * r + 5.0000001201e-1f;
     float y = p * z + r;
     y = y + 1.0f;
-    return (y * __builtin_bit_cast(float, ((int)fn + 126) << 23)) * 2.0f;  // 2^n as 2^(n-1) * 2: n = 128 has no float of its own
+    const float e = (y * __builtin_bit_cast(float, ((int)fn + 126) << 23)) * 2.0f;  // 2^n as 2^(n-1) * 2: n = 128 has no float of its own
+    return x0 != x0 ? x0 : x0 > 88.72283f ? __builtin_inff() : e;
 }
 __device__ __forceinline__ float sigmoid_det(float x) { return 1.0f / (1.0f + exp_det(-x)); }  // kernSigmoid, DevFunc.cu:48
 
