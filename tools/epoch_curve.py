@@ -4,7 +4,8 @@ The reference's finetune.pl runs BPtrain_Sigmoid once per epoch over the same co
 CV numbers after each (TC/BPtrain.cc:112-139).  This tool does the same with a one-chunk corpus (102,400 samples = 800
 steps of 128 frames, TC/BP_GPU.cu:170-184) at the shipped topology's width: EPOCHS passes on the GPU, on the CPU oracle,
 and on the oracle's MFMA-order twin (the HIP kernels' own summation order with fused multiply-adds: an equally valid
-reading of cublasSgemm, so its distance to the oracle is what ORDER alone does to the trajectory), and prints after
+reading of cublasSgemm, CUDA's expf and powf, so its distance to the oracle is what those choices alone do to the
+trajectory -- and the HIP path must equal it in every bit), and prints after
 every epoch the relative distance of the three logged numbers.  EPOCHS (default 5), CASES (default "1:1.0,1:1.2,0:2.0")."""
 import importlib, os, sys, time
 import numpy as np
@@ -50,8 +51,9 @@ for ml, beta in CASES:
         rr = lambda a, b: max(float(np.sqrt(np.mean((x.astype(np.float64) - y) ** 2) / max(np.mean(y.astype(np.float64) ** 2), 1e-300)))
                               for x, y in zip(a, b))
         print("  epoch %d: CV sqerr/frame %.4f | HIP vs oracle %.1e %.1e %.1e, weights %.1e | MFMA-order twin vs oracle %.1e %.1e %.1e, weights %.1e"
-              " | HIP vs twin (libm only) %.1e %.1e %.1e, weights %.1e   (%.0f s)"
+              " | HIP vs twin %.1e %.1e %.1e, weights %.1e, every bit equal: %s   (%.0f s)"
               % (ep, o[0] / 3000, rel(h[0], o[0]), rel(h[1], o[1]), rel(h[2], o[2]), rr(w_h, w_o),
                  rel(tw[0], o[0]), rel(tw[1], o[1]), rel(tw[2], o[2]), rr(w_t, w_o),
-                 rel(h[0], tw[0]), rel(h[1], tw[1]), rel(h[2], tw[2]), rr(w_h, w_t), time.time() - t0), flush=True)
+                 rel(h[0], tw[0]), rel(h[1], tw[1]), rel(h[2], tw[2]), rr(w_h, w_t),
+                 all(np.array_equal(a, b) for a, b in zip(w_h, w_t)) and h == tw, time.time() - t0), flush=True)
     eng.close(); ora.close(); twin.close()
