@@ -28,7 +28,10 @@ runs may see one where another sees none; its size is derived from the update ru
 larger -- and the three CV log lines to 1e-4 relative -- the north_star figure -- OR
 K_TWIN x the twins' distance where that is larger.  The first two steps of an epoch, before the growth sets in, are
 held to the plain 5e-5 by tests/test_gpu_parity.py::test_baseline_net_two_steps[1-1.0] and the loss chain to 0 ulp by
-tests/test_gpu_loss_ulps.py."""
+tests/test_gpu_loss_ulps.py.
+
+And, since r04, one bound that is no bound at all: the weights file every epoch leaves must equal the net of the oracle's
+MFMA-order twin (the HIP kernels' summation order, exponential and power restated on the CPU) IN EVERY BIT."""
 import json
 import os
 import re
@@ -81,7 +84,7 @@ def test_bptrain_sigmoid_as_finetune_pl_drives_it_epochs_1_2_11(pkg, pyoracle, t
                            "1", "2", "5"], stdout=subprocess.DEVNULL)
 
     probe = pkg.BPGpu(1, 0, ls, B, 0.1, 0.9, 1e-5, *hostlib.read_wts(str(init), ls), 1.0, 1)
-    s_out = probe.out_slabs()                                      # split of the output-layer GEMM: the MFMA-order twin restates it
+    s_out, plan = probe.out_slabs(), probe.gemm_plan()             # the output layer's slabs, each layer's GEMM kernel: the MFMA-order twin restates them
     probe.close()
     K_TWIN = 4.0
     cwd = os.getcwd()
@@ -118,7 +121,7 @@ def test_bptrain_sigmoid_as_finetune_pl_drives_it_epochs_1_2_11(pkg, pyoracle, t
 
             def oracle_epoch(split=1, order="ref"):
                 pyoracle.set_gemm_split(split)
-                pyoracle.set_gemm_order(order, s_out)
+                pyoracle.set_gemm_order(order, s_out, plan=plan)
                 try:
                     ora = pyoracle.OracleNet(ls, B, *hp, w0, b0)
                     steps = sum(ora.train(inp, tg) for inp, tg in chunks)
@@ -147,7 +150,14 @@ def test_bptrain_sigmoid_as_finetune_pl_drives_it_epochs_1_2_11(pkg, pyoracle, t
             got = [float(re.search(pat + r": (-?[\d.]+)", log).group(1)) for pat in
                    ("CV over. squared error", "CV over. square root squared error", "CV2 over. CV log likelihood")]
             d_hip = dist({"w": ws, "b": bs, "cv": got}, ref)
-            twins = {"split 4": dist(oracle_epoch(split=4), ref), "MFMA order": dist(oracle_epoch(order="hip"), ref)}
+            mfma = oracle_epoch(order="hip")
+            twins = {"split 4": dist(oracle_epoch(split=4), ref), "MFMA order": dist(mfma, ref)}
+            # r04: the executable's weights file IS the MFMA-order twin's net, every bit -- pfile reader, chunk plan, shuffle,
+            # context expansion, normalisation, 40-odd training steps at the shipped objective and the .wts writer, pinned
+            # to a CPU model of the same epoch (summation order, exponential and power as the HIP kernels take them)
+            for l in range(len(ls) - 1):
+                assert np.array_equal(ws[l], mfma["w"][l]), (epoch, "weights", l + 1)
+                assert np.array_equal(bs[l], mfma["b"][l]), (epoch, "bias", l + 1)
             yard = {"w": max(t["w"] for t in twins.values()), "b": max(t["b"] for t in twins.values()),
                     "cv": [max(t["cv"][i] for t in twins.values()) for i in range(3)]}
             fmt = lambda d: "weights %.1e biases %.1e | CV %.1e %.1e %.1e" % (d["w"], d["b"], *d["cv"])
