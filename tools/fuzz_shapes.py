@@ -22,6 +22,7 @@ def relmax(a, b):
 
 
 worst = 0.0
+n_bits = 0
 for case in range(N):
     dim = int(rng.integers(3, 40)); ctx = int(rng.choice([1, 3, 5, 7]))
     nh = int(rng.integers(0, 5))
@@ -72,10 +73,31 @@ for case in range(N):
         # in its last bits (GEMM summation order) flips one such element and moves a bias by ~1e-4 of max|b| in a few
         # steps (SEED=22 case 12: out equal to 7e-7, alpha to 1e-7, one of 7,424 gradient elements with the other sign)
         tol = 5e-4
+    # ... and against the oracle's MFMA-order twin (the HIP kernels' summation order, exponential and power restated on the
+    # CPU) EVERY BIT must agree: one device at any loss; emulated worlds with a factor exchange at the MMSE losses (the
+    # ML statistic is summed rank by rank there, the gradient all-reduce sums per-rank chains: other orders by design)
+    bits = ""
+    if world == 1 or (ml == 0 and dp in ("gather", "shard", "shard_a2a")):
+        pyoracle.set_gemm_order("hip", eng.out_slabs(), plan=eng.gemm_plan())
+        try:
+            tw = pyoracle.OracleNet(ls, world * B, *HP, beta, ml, ws, bs)
+            assert tw.train(inp, tg) == steps
+            wt, bt = tw.get_weights()
+            same = all(np.array_equal(a, b) for a, b in zip(list(we) + list(be), list(wt) + list(bt)))
+            tw.close()
+        finally:
+            pyoracle.set_gemm_order("ref")
+        bits = "  = twin bitwise" if same else "  DIFFERS FROM THE TWIN"
+        n_bits += 1
+        assert same, (case, ls, B, ml, beta, world, dp)
+    if bits and B < 7:
+        # a one-frame minibatch on a deep net: the distance to the documented order is the ORACLE's own order sensitivity
+        # (the HIP path equals the twin in every bit) -- SEED=91 case 92, 5 layers, 4 steps of one frame: 3.4e-4 of max|W|
+        tol = 2e-3
     tag = "ok " if err < tol else "BAD"
-    print("%s case %2d: layers %-28s B %3d  loss (%d,%.1f) steps %d world %d%s%s  err %.1e" %
-          (tag, case, ls, B, ml, beta, steps, world, " " + dp if dp else "", " frames" if frames_mode else "", err),
+    print("%s case %2d: layers %-28s B %3d  loss (%d,%.1f) steps %d world %d%s%s  err %.1e%s" %
+          (tag, case, ls, B, ml, beta, steps, world, " " + dp if dp else "", " frames" if frames_mode else "", err, bits),
           flush=True)
     assert err < tol
     eng.close(); ora.close()
-print("all %d cases within tolerance; worst %.1e" % (N, worst))
+print("all %d cases within tolerance; worst %.1e; %d of them checked against the MFMA-order twin: every bit equal" % (N, worst, n_bits))
