@@ -190,6 +190,17 @@ void ora_set_gemm_plan(int layer, int fwd_waves, int dx_waves) {
     g_hip_fwd_waves[layer] = fwd_waves == 1 ? 1 : 4;
     g_hip_dx_waves[layer] = dx_waves == 1 ? 1 : 4;
 }
+/* Data-parallel form of the MFMA-order twin (order 1 only): what `world` ranks with B = n / world frames each leave when
+ * their partial results meet in RANK ORDER -- which is what the one-GPU emulation of a world does
+ * (mlggd_debug_fake_world; a real all-reduce's order is RCCL's own).  The ML statistic: every rank sums its frames by
+ * the wavefront reduction of csrc/kernels.hip.h k_colsum (lane l takes frames l, l + 64, ...; six butterfly steps),
+ * the ranks' sums are added in rank order.  allreduce = 1 (gradient all-reduce): dW and the bias gradient are
+ * per-rank chains over the rank's own frames, added in rank order; 0 (factor exchanges): one chain over all frames. */
+static int g_dp_world = 1, g_dp_allreduce = 0;
+void ora_set_dp_twin(int world, int allreduce) {
+    g_dp_world = world < 1 ? 1 : world;
+    g_dp_allreduce = allreduce != 0;
+}
 #define ORA_FMA __attribute__((target("fma"))) /* fmaf as ONE instruction; -ffp-contract=off still keeps every other a*b+c unfused */
 static int ceil32i(int x) { return (x + 31) & ~31; }
 
@@ -790,6 +801,28 @@ void ora_loss_colsum(ora_net *net, int n, const float *targ, float *colsum) {
             net->errorabsolute[i] = fabsf(net->realerror[i]);
             net->errorabsolute2[i] = lpow(net->errorabsolute[i], beta);
         }
+    if (g_gemm_order == 1 && g_dp_world > 1 && n % g_dp_world == 0) { /* k_colsum per rank, ranks in order */
+        const int B = n / g_dp_world;
+        for (int d = 0; d < D; d++) {
+            float tot = 0.0f;
+            for (int r = 0; r < g_dp_world; r++) {
+                float lane[64];
+                for (int l = 0; l < 64; l++) {
+                    float s = 0.0f;
+                    for (int b = l; b < B; b += 64) s += net->errorabsolute2[(size_t)(r * B + b) * D + d];
+                    lane[l] = s;
+                }
+                for (int off = 32; off > 0; off >>= 1) {
+                    float nx[64];
+                    for (int l = 0; l < 64; l++) nx[l] = lane[l] + lane[l ^ off];
+                    memcpy(lane, nx, sizeof(lane));
+                }
+                tot = r == 0 ? lane[0] : tot + lane[0];
+            }
+            colsum[d] = tot;
+        }
+        return;
+    }
     for (int d = 0; d < D; d++) {
         float s = net->errorabsolute2[d];
         for (int b = 1; b < n; b++) s += net->errorabsolute2[(size_t)b * D + d];
@@ -861,15 +894,42 @@ void ora_backward(ora_net *net, int n, const float *in) {
 #pragma omp parallel for schedule(static)
             for (size_t i = 0; i < sz; i++) dedx[i] = (1.0f - y[i]) * y[i] * dedy[i];
         }
+        const int ranks = (g_gemm_order == 1 && g_dp_allreduce && g_dp_world > 1 && n % g_dp_world == 0) ? g_dp_world : 1;
         if (g_gemm_order == 1) {
             if (l != 1) gemm_dx_hip(n, K, N, dedx, net->weights[l], net->layer_dedy[l - 1], g_hip_dx_waves[l]);
-            gemm_dw_hip(n, K, N, prev_y, dedx, net->layer_ydedx[l]);
+            if (ranks == 1) {
+                gemm_dw_hip(n, K, N, prev_y, dedx, net->layer_ydedx[l]);
+            } else { /* gradient all-reduce: every rank's chain over its own frames, the ranks added in order */
+                const int B = n / ranks;
+                float *part = (float *)malloc((size_t)K * N * sizeof(float)), *g = net->layer_ydedx[l];
+                for (int r = 0; r < ranks; r++) {
+                    gemm_dw_hip(B, K, N, prev_y + (size_t)r * B * K, dedx + (size_t)r * B * N, r == 0 ? g : part);
+                    if (r > 0) {
+#pragma omp parallel for schedule(static)
+                        for (size_t i = 0; i < (size_t)K * N; i++) g[i] = g[i] + part[i];
+                    }
+                }
+                free(part);
+            }
         } else {
             if (l != 1) gemm_dx(n, K, N, dedx, net->weights[l], net->layer_dedy[l - 1]); /* :430 */
             gemm_dw(n, K, N, prev_y, dedx, net->layer_ydedx[l]);                          /* :432 */
         }
         /* kernAccSumrow, DevFunc.cu:267-285 <- :434 (alpha 0, beta 1; rows summed in order) */
         float *sum = net->layer_sumdedx[l];
+        if (ranks > 1) { /* the bias gradient likewise: per-rank sums in frame order, added in rank order */
+            const int B = n / ranks;
+            for (int j = 0; j < N; j++) {
+                float tot = 0.0f;
+                for (int r = 0; r < ranks; r++) {
+                    float s = sum[j] * 0.0f + 1.0f * dedx[(size_t)r * B * N + j];
+                    for (int b = 1; b < B; b++) s += 1.0f * dedx[(size_t)(r * B + b) * N + j];
+                    tot = r == 0 ? s : tot + s;
+                }
+                sum[j] = tot;
+            }
+            continue;
+        }
         for (int j = 0; j < N; j++) {
             float s = sum[j] * 0.0f + 1.0f * dedx[j];
             for (int b = 1; b < n; b++) s += 1.0f * dedx[(size_t)b * N + j];

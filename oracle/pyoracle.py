@@ -57,6 +57,7 @@ def lib(variant="strict"):
         L.ora_set_gemm_blocked.argtypes = [C.c_int]
         L.ora_set_gemm_order.argtypes = [C.c_int, C.c_int]
         L.ora_set_gemm_plan.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.ora_set_dp_twin.argtypes = [C.c_int, C.c_int]
         L.ora_exp_det_array.argtypes = [_fp, _fp, C.c_long, C.c_int]
         L.ora_pow_det_array.argtypes = [_fp, C.c_float, _fp, C.c_long]
         if "OMP_NUM_THREADS" not in os.environ:
@@ -233,17 +234,21 @@ def set_gemm_blocked(on, variant="strict"):
     lib(variant).ora_set_gemm_blocked(1 if on else 0)
 
 
-def set_gemm_order(order, s_out=1, variant="strict", plan=None):
+def set_gemm_order(order, s_out=1, variant="strict", plan=None, dp_world=1, dp_allreduce=False):
     """MFMA-order twin (process-wide for that library): order "hip" / 1 = the HIP kernels' own summation order with
     fused multiply-adds -- forward / dX reductions over the 4 waves' contiguous ranges, the output layer over `s_out`
     slabs x 4 waves (the engine's choice: BPGpu.out_slabs()), dW over the frames in order; "ref" / 0 = the documented
     orders every parity test compares against.  With order "hip" the GEMMs of the HIP path equal this CPU model bit for
     bit (tests/test_gpu_mfma_order.py), which leaves libm (expf, powf) as the only difference between the two.
     plan: [(fwd_waves, dx_waves)] per layer 1..L-1 (BPGpu.gemm_plan()): 4 = reduction over the 4 waves of a 32 x 32-tile
-    workgroup (default), 1 = the 64 x 64-tile kernels' single chain per output element."""
+    workgroup (default), 1 = the 64 x 64-tile kernels' single chain per output element.
+    dp_world > 1: the data-parallel form -- `dp_world` ranks of bunchsize / dp_world frames whose ML statistic (k_colsum's
+    wavefront reduction per rank) and, with dp_allreduce, weight / bias gradients meet in rank order, as the one-GPU
+    emulation of a world (BPGpu.fake_world) does."""
     lib(variant).ora_set_gemm_order(1 if order in (1, "hip") else 0, int(s_out))
     for l, (fw, dx) in enumerate(plan or [], start=1):  # BPGpu.gemm_plan(): which GEMM kernel each layer takes
         lib(variant).ora_set_gemm_plan(l, int(fw), int(dx))
+    lib(variant).ora_set_dp_twin(int(dp_world), 1 if dp_allreduce else 0)
 
 
 def exp_det(x, sigmoid=False, variant="strict"):

@@ -99,6 +99,19 @@ def test_config4_eight_ranks_at_the_real_shape(pkg, pyoracle, synth, mode):
     sq, ab, ll = eng.cv_all(cin, ctarg)
     assert abs(sq - ora.cv_sqerr(cin, ctarg)) <= 1e-4 * abs(sq)
     assert abs(ll - ora.cv_loglik(cin, ctarg)) <= 1e-4 * abs(ll)
+    # and EVERY BIT of the oracle's MFMA-order twin in its data-parallel form: eight ranks' k_colsum wavefront sums of the
+    # ML statistic met in rank order, and -- gradient all-reduce -- their weight / bias gradient chains likewise
+    pyoracle.set_gemm_order("hip", eng.out_slabs(), plan=eng.gemm_plan(), dp_world=world, dp_allreduce=mode == "allreduce")
+    try:
+        twin = pyoracle.OracleNet(ls, world * B, *HP, 1.2, 1, ws, bs)
+        assert twin.train(inp, targ) == steps
+        wt, bt = twin.get_weights()
+        for l in range(len(we)):
+            assert np.array_equal(we[l], wt[l]) and np.array_equal(be[l], bt[l]), l
+        assert np.array_equal(eng.scalefactor(), twin.tensor("scalefactor"))
+        twin.close()
+    finally:
+        pyoracle.set_gemm_order("ref")
     eng.close()
     ora.close()
 

@@ -74,11 +74,11 @@ for case in range(N):
         # steps (SEED=22 case 12: out equal to 7e-7, alpha to 1e-7, one of 7,424 gradient elements with the other sign)
         tol = 5e-4
     # ... and against the oracle's MFMA-order twin (the HIP kernels' summation order, exponential and power restated on the
-    # CPU) EVERY BIT must agree: one device at any loss; emulated worlds with a factor exchange at the MMSE losses (the
-    # ML statistic is summed rank by rank there, the gradient all-reduce sums per-rank chains: other orders by design)
+    # CPU) EVERY BIT must agree -- one device, and emulated worlds in the twin's data-parallel form (the ranks' ML
+    # statistics, and with the gradient all-reduce their weight / bias gradients, met in rank order)
     bits = ""
-    if world == 1 or (ml == 0 and dp in ("gather", "shard", "shard_a2a")):
-        pyoracle.set_gemm_order("hip", eng.out_slabs(), plan=eng.gemm_plan())
+    if True:
+        pyoracle.set_gemm_order("hip", eng.out_slabs(), plan=eng.gemm_plan(), dp_world=world, dp_allreduce=dp == "allreduce")
         try:
             tw = pyoracle.OracleNet(ls, world * B, *HP, beta, ml, ws, bs)
             assert tw.train(inp, tg) == steps
