@@ -55,6 +55,11 @@ struct ora_net {
     float *layer_dedy[ORA_MAXLAYER], *layer_dedx[ORA_MAXLAYER];
     float *layer_ydedx[ORA_MAXLAYER], *layer_sumdedx[ORA_MAXLAYER];
     int cap_frames; /* rows allocated for the per-bunch buffers */
+    /* dropout (BP_GPU.cu:344-355, 484-501); the generator is the HIP engine's counter hash, not cuRAND (ora_set_dropout) */
+    int dropoutflag;
+    float visible_omit, hid_omit;
+    unsigned seed, step_counter;
+    float *in_drop; /* the minibatch's input rows with the visible units dropped (the reference masks `in` in place) */
 };
 
 static float *zalloc(size_t n) { /* devnew_vf zero-fills, BP_GPU.cu:528-543 */
@@ -140,6 +145,7 @@ void ora_destroy(ora_net *net) {
         free(net->layer_dedy[l]); free(net->layer_dedx[l]);
         free(net->layer_ydedx[l]); free(net->layer_sumdedx[l]);
     }
+    free(net->in_drop);
     free(net);
 }
 
@@ -765,17 +771,61 @@ __attribute__((optimize("fp-contract=off"))) void ora_exp_det_array(const float 
 }
 
 /* ---- forward: BP_GPU.cu:334-369 (train) and :467-509 (cv) ---- */
-void ora_forward(ora_net *net, int n, const float *in) {
+/* Dropout.  kernDropout (DevFunc.cu:26-34 <- BP_GPU.cu:344-355): in[i] = 0 where u_i < p, no rescale; CV scales the
+ * weights by the keep-probability around each GEMM instead (kernWeightMultiP, DevFunc.cu:19-25 <- BP_GPU.cu:484-501 --
+ * W * keep, then W * (1 / keep): a round trip that does not restore every bit, as in the reference).
+ * DOCUMENTED DEVIATION: the reference draws u from cuRAND's default generator, whose stream cannot be matched; the HIP
+ * engine draws it from a counter-based hash of (seed, step, layer, element) -- csrc/kernels.hip.h k_dropout -- and the
+ * oracle restates THAT generator, in both of its readings, so dropout runs can be compared at all.  The element index is
+ * the engine's: unit * ceil32(bunchsize) + frame. */
+void ora_set_dropout(ora_net *net, int dropoutflag, float visible_omit, float hid_omit, int random_seed) {
+    net->dropoutflag = dropoutflag == 1;
+    net->visible_omit = visible_omit;
+    net->hid_omit = hid_omit;
+    net->seed = (unsigned)random_seed;
+}
+static unsigned mix32(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+static void dropout_rows(const ora_net *net, float *y, int n, int N, float p, int layer) {
+    const unsigned Bp = (unsigned)((net->bunchsize + 31) & ~31), step = net->step_counter * 16u + (unsigned)layer;
+    const unsigned base = mix32(net->seed ^ (step * 0x9e3779b9u));
+    for (int b = 0; b < n; b++)
+        for (int u = 0; u < N; u++) {
+            const unsigned hsh = mix32(base ^ ((unsigned)u * Bp + (unsigned)b));
+            const float r = (float)(hsh >> 8) * (1.0f / 16777216.0f);
+            if (r < p) y[(size_t)b * N + u] = 0.0f;
+        }
+}
+static void scale_weights(float *w, size_t n, float p) {
+    for (size_t i = 0; i < n; i++) w[i] = w[i] * p;
+}
+
+/* mode 0: training forward (dropout masks when enabled); 1: CV forward (weight scaling when enabled) */
+static void forward_impl(ora_net *net, int n, const float *in, int cv) {
     ensure_frames(net, n);
     const int L = net->numlayers;
+    const int drop = net->dropoutflag && !cv, cvscale = net->dropoutflag && cv;
+    if (drop) { /* :344-347: the visible units of this minibatch */
+        const size_t sz = (size_t)n * net->layersizes[0];
+        net->in_drop = (float *)realloc(net->in_drop, (sz ? sz : 1) * sizeof(float));
+        memcpy(net->in_drop, in, sz * sizeof(float));
+        dropout_rows(net, net->in_drop, n, net->layersizes[0], net->visible_omit, 0);
+        in = net->in_drop;
+    }
     for (int l = 1; l < L; l++) {
         const int N = net->layersizes[l], K = net->layersizes[l - 1];
+        if (drop && l > 1) dropout_rows(net, net->layer_y[l - 1], n, K, net->hid_omit, l - 1); /* :350-353 */
+        const float keep = 1.0f - (l == 1 ? net->visible_omit : net->hid_omit);
+        if (cvscale) scale_weights(net->weights[l], (size_t)K * N, keep); /* :484-489 */
         const float *prev_y = (l == 1) ? in : net->layer_y[l - 1];
         float *x = net->layer_x[l];
         /* kernMultiCopy, DevFunc.cu:134-149 <- BP_GPU.cu:360 */
         for (int b = 0; b < n; b++) memcpy(x + (size_t)b * N, net->bias[l], N * sizeof(float));
         if (g_gemm_order == 1) gemm_fwd_hip(n, K, N, prev_y, net->weights[l], x, l == L - 1 ? g_hip_s_out : 1, g_hip_fwd_waves[l]);
         else gemm_fwd(n, K, N, prev_y, net->weights[l], x); /* :361 */
+        if (cvscale) scale_weights(net->weights[l], (size_t)K * N, 1.0f / keep); /* :496-501 */
         if (l != L - 1) {
             /* kernSigmoid, DevFunc.cu:36-51 <- :364 */
             float *y = net->layer_y[l];
@@ -787,6 +837,7 @@ void ora_forward(ora_net *net, int n, const float *in) {
         }
     }
 }
+void ora_forward(ora_net *net, int n, const float *in) { forward_impl(net, n, in, 0); }
 
 /* Deverror + Devabsolutevalus + Devindex2 + DevSumcol: BP_GPU.cu:413-416
  * (kernerror DevFunc.cu:399-409, kernabsolutevalus :186-191, kernindex2 :219-227,
@@ -883,6 +934,7 @@ void ora_loss_grad(ora_net *net, int n, int n_global, const float *targ, const f
  * computation as the reference's per-layer interleaving. */
 void ora_backward(ora_net *net, int n, const float *in) {
     const int L = net->numlayers;
+    if (net->dropoutflag && net->in_drop) in = net->in_drop; /* the reference masked `in` itself (:346): dW_1 sees the dropped rows */
     for (int l = L - 1; l > 0; l--) {
         const int N = net->layersizes[l], K = net->layersizes[l - 1];
         const float *prev_y = (l == 1) ? in : net->layer_y[l - 1];
@@ -976,6 +1028,7 @@ void ora_train_bunch(ora_net *net, int n, const float *in, const float *targ) {
     free(tmp);
     ora_backward(net, n, in);
     ora_apply_update(net, n);
+    net->step_counter++;
 }
 
 /* BP_GPU::train, BP_GPU.cu:152-185 */
@@ -995,10 +1048,10 @@ int ora_train(ora_net *net, int n_frames, const float *in, const float *targ) {
     return trained;
 }
 
-/* BP_GPU::cv_bunch_single, BP_GPU.cu:442-512 (dropoutflag==0 path) */
+/* BP_GPU::cv_bunch_single, BP_GPU.cu:442-512 */
 void ora_cv_bunch(ora_net *net, int n, const float *in, float *out) {
     const int D = net->layersizes[net->numlayers - 1];
-    ora_forward(net, n, in);
+    forward_impl(net, n, in, 1);
     memcpy(out, net->out, (size_t)n * D * sizeof(float));
 }
 

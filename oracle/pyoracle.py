@@ -33,6 +33,7 @@ def lib(variant="strict"):
         L.ora_create.argtypes = [C.c_int, C.POINTER(C.c_int), C.c_int, C.c_float, C.c_float,
                                  C.c_float, C.c_float, C.c_int, _fpp, _fpp]
         L.ora_destroy.argtypes = [C.c_void_p]
+        L.ora_set_dropout.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int]
         L.ora_train.restype = C.c_int
         L.ora_train.argtypes = [C.c_void_p, C.c_int, _fp, _fp]
         L.ora_train_bunch.argtypes = [C.c_void_p, C.c_int, _fp, _fp]
@@ -112,7 +113,7 @@ class OracleNet:
     """Mirror of the reference's class BP_GPU (BP_GPU.h:45-70) on the CPU oracle."""
 
     def __init__(self, layersizes, bunchsize, lrate, momentum, weightcost, shapefactor, MLflag,
-                 weights, bias, variant="strict"):
+                 weights, bias, variant="strict", dropoutflag=0, visible_omit=0.0, hid_omit=0.0, random_seed=0):
         self._lib = lib(variant)
         self.layersizes = [int(x) for x in layersizes]
         self.L = len(self.layersizes)
@@ -127,6 +128,8 @@ class OracleNet:
         self._h = self._lib.ora_create(self.L, ls, self.bunchsize, lrate, momentum, weightcost,
                                    shapefactor, int(MLflag), _ptr_array(self._w), _ptr_array(self._b))
         assert self._h
+        if dropoutflag == 1:  # the HIP engine's counter-hash generator, restated (documented deviation from cuRAND)
+            self._lib.ora_set_dropout(self._h, 1, visible_omit, hid_omit, int(random_seed))
 
     def close(self):
         if self._h:

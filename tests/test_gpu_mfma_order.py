@@ -275,3 +275,45 @@ def test_dw_over_256_and_512_frames_equals_the_twin_bitwise(pkg, pyoracle, K, D,
         pyoracle.set_gemm_order("ref")
         eng.close()
     assert bad == 0
+
+
+@pytest.mark.parametrize("ml,beta", [(0, 2.0), (1, 1.0)])
+def test_dropout_runs_equal_the_twin_bit_for_bit(pkg, pyoracle, synth, ml, beta):
+    """a25 (BP_GPU.cu:344-355, 484-501).  The reference's cuRAND stream cannot be matched (documented deviation); the engine
+    draws its uniforms from a counter hash of (seed, step, layer, element), and the oracle restates THAT generator -- so a
+    dropout run is comparable at all: the same masks on both sides, 6 training steps leave the twin's weights in every bit
+    (and the documented-order oracle's to 2e-5), a CV forward pass (weights scaled by the keep-probability around each
+    GEMM) returns the twin's outputs in every bit, and the scale / unscale round trip leaves the same perturbed weights."""
+    ls, B, steps = [257 * 3, 256, 192, 257], 128, 6
+    ws, bs = synth.make_weights(ls, seed=5)
+    inp, targ = synth.make_frames(steps * B, 257, 3, seed=6)
+    kw = dict(dropoutflag=1, visible_omit=0.2, hid_omit=0.5)
+    eng = pkg.BPGpu(77, 0, ls, B, *HP, ws, bs, beta, ml, **kw)
+    ref = pyoracle.OracleNet(ls, B, *HP, beta, ml, ws, bs, random_seed=77, **kw)
+    try:
+        pyoracle.set_gemm_order("hip", eng.out_slabs(), plan=eng.gemm_plan())
+        twin = pyoracle.OracleNet(ls, B, *HP, beta, ml, ws, bs, random_seed=77, **kw)
+        assert eng.train(inp, targ) == steps and twin.train(inp, targ) == steps
+        for l in (1, 2):
+            y = eng.debug_tensor("y", l)
+            assert np.array_equal(y, twin.tensor("y", l, rows=B)), l
+            assert 0.45 < float((y == 0).mean()) < 0.55                      # hid_omit = 0.5 took effect
+        we, be = eng.returnWeights()
+        wt, bt = twin.get_weights()
+        for a, b in zip(list(we) + list(be), list(wt) + list(bt)):
+            assert np.array_equal(a, b)
+        out = eng.forward(inp[:300])                                        # CV: W * keep, GEMM, W * (1 / keep) -- per bunch,
+        want = np.concatenate([twin.cv_forward(inp[i:min(i + B, 300)]) for i in range(0, 300, B)])   # as CrossValid loops them
+        assert np.array_equal(out, want)
+        for a, b in zip(eng.returnWeights()[0], twin.get_weights()[0]):      # the round trip's rounding, bit for bit
+            assert np.array_equal(a, b)
+        assert any(not np.array_equal(a, b) for a, b in zip(eng.returnWeights()[0], we))   # ... and it is not the identity
+        pyoracle.set_gemm_order("ref")
+        assert ref.train(inp, targ) == steps
+        for a, b in zip(we, ref.get_weights()[0]):
+            assert float(np.abs(a - b).max() / np.abs(b).max()) < 2e-5
+        twin.close()
+    finally:
+        pyoracle.set_gemm_order("ref")
+        ref.close()
+        eng.close()
