@@ -2471,7 +2471,7 @@ int mlggd_dp_mode(mlggd_handle e, int *mode) {
 // ("powf" "expf" "sigmoid" "div"); tests measure their distance to the oracle's host libm in ulps.
 int mlggd_debug_math(mlggd_handle e, const char *fn, const float *x, float y, float *out, size_t n) {
     if (!e || !fn || (n > 0 && (!x || !out))) return fail(MLGGD_ERR_ARG, "NULL argument");
-    const int f = !strcmp(fn, "powf") ? 0 : !strcmp(fn, "expf") ? 1 : !strcmp(fn, "sigmoid") ? 2 : !strcmp(fn, "div") ? 3 : !strcmp(fn, "exp_det") ? 4 : !strcmp(fn, "pow_det") ? 5 : -1;
+    const int f = !strcmp(fn, "powf") ? 0 : !strcmp(fn, "expf") ? 1 : !strcmp(fn, "sigmoid") ? 2 : !strcmp(fn, "div") ? 3 : !strcmp(fn, "exp_det") ? 4 : !strcmp(fn, "pow_det") ? 5 : !strcmp(fn, "sigmoid4") ? 6 : -1;
     if (f < 0) return fail(MLGGD_ERR_ARG, "unknown function '%s'", fn);
     if (n == 0) return MLGGD_OK;
     HIPCHK(hipSetDevice(e->device));

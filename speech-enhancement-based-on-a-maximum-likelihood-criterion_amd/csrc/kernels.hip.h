@@ -123,6 +123,53 @@ __device__ __forceinline__ float exp_det(float x0) {
     return x0 != x0 ? x0 : x0 > 88.72283f ? __builtin_inff() : e;
 }
 __device__ __forceinline__ float sigmoid_det(float x) { return 1.0f / (1.0f + exp_det(-x)); }  // kernSigmoid, DevFunc.cu:48
+// Two elements at a time: the SAME operations per element, issued as packed fp32 instructions (v_pk_mul_f32 /
+// v_pk_add_f32 are two independent IEEE operations per lane) -- the forward epilogues' four sigmoids per thread in half the
+// multiply / add instructions (-0.8 us per step in a same-box A/B); results are those of exp_det bit for bit
+// (tests/test_gpu_loss_ulps.py compares both forms).
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t exp_det2(f32x2_t x0) {
+    f32x2_t x;
+    x.x = x0.x < -85.5f ? -85.5f : x0.x;
+    x.y = x0.y < -85.5f ? -85.5f : x0.y;
+    x.x = x.x > 88.72283f ? 88.72283f : x.x;
+    x.y = x.y > 88.72283f ? 88.72283f : x.y;
+    x.x = x0.x != x0.x ? 0.0f : x.x;
+    x.y = x0.y != x0.y ? 0.0f : x.y;
+    const f32x2_t t = x * 1.44269504f + 0.5f;
+    f32x2_t fn;
+    fn.x = __builtin_floorf(t.x);
+    fn.y = __builtin_floorf(t.y);
+    f32x2_t r = x - fn * 0.693359375f;
+    r = r - fn * -2.12194440e-4f;
+    const f32x2_t z = r * r;
+    f32x2_t p = {1.9875691500e-4f, 1.9875691500e-4f};
+    p = p * r + 1.3981999507e-3f;
+    p = p * r + 8.3334519073e-3f;
+    p = p * r + 4.1665795894e-2f;
+    p = p * r + 1.6666665459e-1f;
+    p = p * r + 5.0000001201e-1f;
+    f32x2_t y = p * z + r;
+    y = y + 1.0f;
+    f32x2_t sc;
+    sc.x = __builtin_bit_cast(float, ((int)fn.x + 126) << 23);
+    sc.y = __builtin_bit_cast(float, ((int)fn.y + 126) << 23);
+    f32x2_t e = (y * sc) * 2.0f;
+    e.x = x0.x != x0.x ? x0.x : x0.x > 88.72283f ? __builtin_inff() : e.x;
+    e.y = x0.y != x0.y ? x0.y : x0.y > 88.72283f ? __builtin_inff() : e.y;
+    return e;
+}
+// y = sigmoid(v + b) for the four values of a thread, 0 where `live` is false (pad units)
+__device__ __forceinline__ float4 sigmoid_det4(float4 v, float b, bool live) {
+    const f32x2_t lo = {-(v.x + b), -(v.y + b)}, hi = {-(v.z + b), -(v.w + b)};
+    const f32x2_t e0 = exp_det2(lo) + 1.0f, e1 = exp_det2(hi) + 1.0f;
+    float4 y;
+    y.x = live ? 1.0f / e0.x : 0.0f;
+    y.y = live ? 1.0f / e0.y : 0.0f;
+    y.z = live ? 1.0f / e1.x : 0.0f;
+    y.w = live ? 1.0f / e1.y : 0.0f;
+    return y;
+}
 
 // The power of the loss chain (pow_or_self below; kernindex2 / kernfunc2, DevFunc.cu:219-227,468-489): pow_det, x^y (x >= 0) as exp(y log x) in IEEE DOUBLE operations only -- adds, multiplies,
 // one division, one floor, exact bit manipulation; no fused multiply-add, no libm, no hardware transcendental -- so that
@@ -524,11 +571,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &A, const int bid, float 
             *reinterpret_cast<float4 *>(&slab[((size_t)s * Np + n0 + row) * Bp + b0 + col4]) = v4;
         } else {
             const int n = n0 + row;
-            float4 y4;  // kernSigmoid, DevFunc.cu:48
-            y4.x = (n < N) ? sigmoid_det(v4.x + bias_row) : 0.0f;
-            y4.y = (n < N) ? sigmoid_det(v4.y + bias_row) : 0.0f;
-            y4.z = (n < N) ? sigmoid_det(v4.z + bias_row) : 0.0f;
-            y4.w = (n < N) ? sigmoid_det(v4.w + bias_row) : 0.0f;
+            const float4 y4 = sigmoid_det4(v4, bias_row, n < N);  // kernSigmoid, DevFunc.cu:48
             *reinterpret_cast<float4 *>(&Yt_out[(size_t)n * Bp + b0 + col4]) = y4;
             tileT[col4][row] = y4.x;
             tileT[col4 + 1][row] = y4.y;
@@ -1703,13 +1746,13 @@ __global__ __launch_bounds__(256) void k_apply_update(float *__restrict__ Wt, fl
 // array, so a test can measure in ulps how far ocml's powf / expf sit from the correctly rounded result and from
 // the oracle's glibc -- the only arithmetic of the loss chain that is not IEEE-exact on both sides.
 //   fn 0: powf(x, y)   1: expf(x) (ocml; no kernel uses it any more)   2: sigmoid_det(x), the forward epilogues' sigmoid
-//   3: x / y   4: exp_det(x)   5: pow_det(x, y), the loss chain's power
+//   3: x / y   4: exp_det(x)   5: pow_det(x, y), the loss chain's power   6: the packed form of the sigmoid (sigmoid_det4)
 __global__ __launch_bounds__(256) void k_debug_math(int fn, const float *__restrict__ x, float y, float *__restrict__ out,
                                                     size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float v = x[i];
-    out[i] = fn == 0 ? powf(v, y) : fn == 1 ? expf(v) : fn == 2 ? sigmoid_det(v) : fn == 4 ? exp_det(v) : fn == 5 ? pow_det(v, y) : v / y;
+    out[i] = fn == 0 ? powf(v, y) : fn == 1 ? expf(v) : fn == 2 ? sigmoid_det(v) : fn == 6 ? sigmoid_det4(make_float4(v, v, v, v), 0.0f, true).z : fn == 4 ? exp_det(v) : fn == 5 ? pow_det(v, y) : v / y;
 }
 
 // keeps one wave busy for `ticks` of the 100 MHz wall clock (bounded: at most `ticks` iterations of a loop whose

@@ -188,11 +188,7 @@ __device__ __forceinline__ void fwd64_body(const FwdArgs &A, const int bid, floa
             continue;
         }
         const float bn = bias_pre[q];
-        float4 y4;  // kernSigmoid, DevFunc.cu:48
-        y4.x = (n < N) ? sigmoid_det(v4.x + bn) : 0.0f;
-        y4.y = (n < N) ? sigmoid_det(v4.y + bn) : 0.0f;
-        y4.z = (n < N) ? sigmoid_det(v4.z + bn) : 0.0f;
-        y4.w = (n < N) ? sigmoid_det(v4.w + bn) : 0.0f;
+        const float4 y4 = sigmoid_det4(v4, bn, n < N);  // kernSigmoid, DevFunc.cu:48
         *reinterpret_cast<float4 *>(&Yt_out[(size_t)n * Bp + b0 + 32 * wn + col4]) = y4;
         T[col4][row] = y4.x;
         T[col4 + 1][row] = y4.y;

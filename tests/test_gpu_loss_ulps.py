@@ -99,7 +99,7 @@ def test_device_powf_and_expf_in_ulps(pkg, pyoracle, synth):
     # exponential sits from the correctly rounded one is measured, not assumed
     v = np.concatenate([rng.normal(0, 4, 100000), rng.uniform(-100, 100, 20000),
                         [0.0, -0.0, 88.72283, 88.8, -85.5, -87.4, -200.0, 200.0, 1e-30, -1e-30]]).astype(np.float32)
-    for fn, sig in (("exp_det", False), ("sigmoid", True)):
+    for fn, sig in (("exp_det", False), ("sigmoid", True), ("sigmoid4", True)):   # sigmoid4: the epilogues' packed two-at-a-time form
         assert np.array_equal(eng.debug_math(fn, v).view(np.uint32), pyoracle.exp_det(v, sigmoid=sig).view(np.uint32)), fn
     inr = np.abs(v) < 85.5
     d = ulp_dist(eng.debug_math("exp_det", v)[inr], np.exp(v[inr].astype(np.float64)).astype(np.float32))
