@@ -1,3 +1,4 @@
+"""A/B of MLGGD_STAGE_AHEAD (the next minibatch's input staged beside the loss kernel) for the MMSE and the ML-GGD step."""
 import importlib, os, sys, time
 import numpy as np
 sys.path.insert(0, os.getcwd())
