@@ -333,8 +333,8 @@ def test_epoch_horizon_one_full_chunk_of_800_steps(pkg, pyoracle, synth, ml, bet
         K_TWIN = 4.0
         # three twins of the oracle: reductions as 4 / 7 contiguous partial sums, and the MFMA-order twin -- the HIP
         # kernels' own summation order with fused multiply-adds (bit-identical GEMMs, tests/test_gpu_mfma_order.py), so
-        # its distance to the oracle is what the HIP path's ORDER alone does to this trajectory; the HIP path's distance
-        # to IT is what libm alone (expf, powf) adds
+        # its distance to the oracle is what the HIP path's choices (summation order, IEEE-only exponential and power)
+        # do to this trajectory; the HIP path's distance to IT must be zero, in every bit (r04: exp_det, pow_det)
         names = ("split 4", "split 7", "MFMA order") if beta < 1.0 else ("split 4", "MFMA order")  # (an 800-step oracle run takes ~20-40 s)
         runs = [oracle_run(4)] + ([oracle_run(7)] if beta < 1.0 else []) + [oracle_run(1, "hip")]
         twins = [dist(r, ora) for r in runs]
@@ -343,7 +343,7 @@ def test_epoch_horizon_one_full_chunk_of_800_steps(pkg, pyoracle, synth, ml, bet
             print("   oracle order twin (%s) vs oracle: sqerr %.1e abserr %.1e loglik %.1e | alpha relrms %.1e relmax %.1e | "
                   "weights relrms %.1e relmax %.1e" % (nm, t["sq"], t["ab"], t["ll"], t["alpha"], t["alpha_max"], t["w"], t["w_max"]))
         t = dist(hip, runs[-1])
-        print("   HIP vs the MFMA-order twin (libm only): sqerr %.1e abserr %.1e loglik %.1e | alpha relrms %.1e relmax %.1e | "
+        print("   HIP vs the MFMA-order twin (must be zero): sqerr %.1e abserr %.1e loglik %.1e | alpha relrms %.1e relmax %.1e | "
               "weights relrms %.1e relmax %.1e" % (t["sq"], t["ab"], t["ll"], t["alpha"], t["alpha_max"], t["w"], t["w_max"]))
         # beta = 0.9, measured r03: HIP vs oracle 8.7e-5 / 5.2e-5 / 9.4e-5 (all three inside the north_star's 1e-4 this
         # time; r02's build: 1.05e-4 on the first), twins 3.4e-5 / 2.9e-5 / 3.8e-5 and 3.0e-5 / 3.0e-6 / 1.6e-5 -- the twins
@@ -354,8 +354,8 @@ def test_epoch_horizon_one_full_chunk_of_800_steps(pkg, pyoracle, synth, ml, bet
         # jumps by 2 / sum|e| where an error crosses zero, so alpha and the weights drift the same way (HIP vs oracle
         # alpha relrms 5.4e-4, weights 2.2e-3: bounded by the twins like beta = 0.9) -- while the three numbers the
         # reference LOGS stay at 2.7e-5 / 2.7e-5 / 1.9e-5 and are held to the north_star's plain 1e-4.
+        # bit for bit the MFMA-order twin, all 800 steps, whatever the distance to the documented order
         if True:
-            # bit for bit the MFMA-order twin, all 800 steps, whatever the distance to the documented order
             assert all(np.array_equal(x, y) for x, y in zip(hip["w"], runs[-1]["w"]))
             assert np.array_equal(hip["alpha"], runs[-1]["alpha"])
             assert hip["sq"] == runs[-1]["sq"] and hip["ab"] == runs[-1]["ab"] and hip["ll"] == runs[-1]["ll"]
