@@ -352,3 +352,73 @@ def test_pow_det_is_the_correctly_rounded_power_but_for_a_few_in_a_million(pyora
     assert np.array_equal(pyoracle.pow_det(np.array([0.0, 5.0, np.inf], np.float32), 0.0), np.ones(3, np.float32))
     assert np.isposinf(pyoracle.pow_det(np.array([3e38], np.float32), 2.0)[0]) and pyoracle.pow_det(np.array([1e-30], np.float32), 2.0)[0] == 0
     assert np.isnan(pyoracle.pow_det(np.array([np.nan], np.float32), 0.9)[0])
+
+
+@pytest.mark.parametrize("allreduce", [False, True])
+def test_data_parallel_form_of_the_twin_is_the_same_step_in_another_order(pyoracle, synth, allreduce):
+    """ora_set_dp_twin(world, allreduce): the MFMA-order twin as `world` ranks whose partial results meet in rank order (the
+    ML statistic by k_colsum's wavefront reduction per rank; with the gradient all-reduce also the dW / bias chains).  It
+    must be the same function as the plain twin up to rounding, must differ from it in bits (another order), and with one
+    rank it must BE the plain twin.  (On the GPU the emulated worlds equal it bit for bit: tests/test_gpu_configs.py.)"""
+    ls, B, world = [3 * 37, 70, 45, 37], 64, 4
+    ws, bs = synth.make_weights(ls, seed=3)
+    inp, targ = synth.make_frames(3 * B, 37, 3, seed=4)
+
+    def run(dp_world, ar):
+        pyoracle.set_gemm_order("hip", 3, dp_world=dp_world, dp_allreduce=ar)
+        try:
+            o = pyoracle.OracleNet(ls, B, *HP, 1.2, 1, ws, bs)
+            assert o.train(inp, targ) == 3
+            r = (o.get_weights(), o.tensor("scalefactor").copy())
+            o.close()
+            return r
+        finally:
+            pyoracle.set_gemm_order("ref")
+
+    (w1, b1), a1 = run(1, False)
+    (wd, bd), ad = run(world, allreduce)
+    (w0, b0), a0 = run(1, allreduce)                                     # one rank: nothing to meet
+    assert all(np.array_equal(x, y) for x, y in zip(w1 + b1, w0 + b0)) and np.array_equal(a1, a0)
+    for x, y in zip(w1, wd):
+        assert relmax(x, y) < 2e-6
+    assert relmax(a1, ad) < 1e-5
+    assert not np.array_equal(a1, ad)                                     # 4 x 16 frames by wavefront sums: other bits
+
+
+def test_dropout_in_the_oracle(pyoracle, synth):
+    """a25 (BP_GPU.cu:344-355, 484-501) in the oracle: omit-probabilities of 0 change nothing (bit for bit); otherwise the
+    input / hidden activations are zeroed at the stated rates with NO rescale, another seed gives another mask, the same
+    seed the same run; the CV pass equals a forward pass over weights scaled by the keep-probabilities, and its scale /
+    unscale round trip leaves the weights within an ulp.  (The generator is the HIP engine's counter hash -- documented
+    deviation from cuRAND -- and the GPU test requires the engine's bits: tests/test_gpu_mfma_order.py.)"""
+    ls, B = [3 * 37, 96, 80, 37], 64
+    ws, bs = synth.make_weights(ls, seed=3)
+    inp, targ = synth.make_frames(2 * B, 37, 3, seed=4)
+    inp = np.abs(inp) + 0.5
+
+    def run(seed, vis, hid, steps=2):
+        o = pyoracle.OracleNet(ls, B, *HP, 2.0, 0, ws, bs, dropoutflag=1, visible_omit=vis, hid_omit=hid, random_seed=seed)
+        assert o.train(inp[:steps * B], targ[:steps * B]) == steps
+        return o
+
+    plain = pyoracle.OracleNet(ls, B, *HP, 2.0, 0, ws, bs)
+    plain.train(inp, targ)
+    z = run(7, 0.0, 0.0)
+    assert all(np.array_equal(x, y) for x, y in zip(plain.get_weights()[0], z.get_weights()[0]))
+    a, b, c = run(7, 0.2, 0.5), run(7, 0.2, 0.5), run(8, 0.2, 0.5)
+    ya = a.tensor("y", 1, rows=B)
+    assert 0.4 < float((ya == 0).mean()) < 0.6                          # hid_omit = 0.5; a sigmoid is never exactly 0
+    kept = ya[ya != 0]
+    assert kept.min() > 0 and kept.max() < 1                            # no rescale: still sigmoid values
+    assert all(np.array_equal(x, y) for x, y in zip(a.get_weights()[0], b.get_weights()[0]))
+    assert not np.array_equal(ya == 0, c.tensor("y", 1, rows=B) == 0)
+    assert any(not np.array_equal(x, y) for x, y in zip(a.get_weights()[0], plain.get_weights()[0]))
+    # CV: W * keep around each GEMM
+    wa = [w.copy() for w in a.get_weights()[0]]
+    out = a.cv_forward(inp[:B])
+    scaled = pyoracle.OracleNet(ls, B, *HP, 2.0, 0, [w * np.float32(k) for w, k in zip(wa, (0.8, 0.5, 0.5))], a.get_weights()[1])
+    assert np.array_equal(out, scaled.cv_forward(inp[:B]))
+    for x, y in zip(a.get_weights()[0], wa):
+        assert np.abs(x - y).max() <= 1.2e-7 * np.abs(y).max()
+    for o in (plain, z, a, b, c, scaled):
+        o.close()
