@@ -526,9 +526,10 @@ def test_dropout_training_and_cv_scaling(pkg, pyoracle, synth):
     eng2.close()
 
 
-def test_enhance_lps_tool_matches_decode_m_math(tmp_path):
+def test_enhance_lps_tool_matches_decode_m_math(pkg, pyoracle, tmp_path):
     """the inference tool vs a float64 restatement of Test_code/decode.m +
-    frame_expand.m (edge-replicated 7-frame context, sigmoid MLP, de-normalisation, HTK out)."""
+    frame_expand.m (edge-replicated 7-frame context, sigmoid MLP, de-normalisation, HTK out) -- and, bit for bit, vs the
+    same pipeline in float32 with the oracle's MFMA-order twin as the MLP."""
     import struct
     subprocess.check_call(["make", "-C", hostlib.HOST, "-s"])
     rng = np.random.default_rng(21)
@@ -560,6 +561,18 @@ def test_enhance_lps_tool_matches_decode_m_math(tmp_path):
             a = 1.0 / (1.0 + np.exp(-a))
     want = a / norm_inv + norm_mean                                    # decode.m:59-61
     assert np.abs(got - want).max() < 2e-4 * np.abs(want).max()
+    # the same in float32 around the oracle's MFMA-order twin (the tool's forward pass runs in bunches of 512 frames)
+    probe = pkg.BPGpu(1, 0, ls, 512, 0.1, 0.9, 1e-5, ws, bs, 2.0, 0)
+    pyoracle.set_gemm_order("hip", probe.out_slabs(), plan=probe.gemm_plan())
+    probe.close()
+    try:
+        tw = pyoracle.OracleNet(ls, 512, 0.1, 0.9, 1e-5, 2.0, 0, ws, bs)
+        y32 = tw.cv_forward(np.ascontiguousarray(x[idx].reshape(n, ctx * dim), np.float32))
+        tw.close()
+    finally:
+        pyoracle.set_gemm_order("ref")
+    want32 = (y32 / norm_inv.astype(np.float32) + norm_mean.astype(np.float32)).astype(np.float32)
+    assert np.array_equal(np.frombuffer(raw[12:], ">f4").reshape(n, dim).astype(np.float32), want32)
 
 
 def test_roctx_ranges_can_be_switched_on(pkg, synth):
